@@ -1,0 +1,173 @@
+/*
+ * hess_abi.h -- C ABI of the MI355X-native Hessian + SIFT-descriptor hot path.
+ *
+ * This is the drop-in boundary of the build: plain C types, pointers and sizes only.
+ * It is what the host-side `SiftGPU` class (include/SiftGPU.h, libsiftgpu.so) binds in
+ * place of the reference's CUDA backend objects.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference tree, src/SiftGPU/...).
+ *
+ * The same signatures, prefixed `hess_cpu_`, are implemented by the CPU oracle
+ * (oracle/hess_oracle.c) so that the parity tests are backend-agnostic.  The oracle is
+ * test infrastructure only; nothing in the product links it.
+ *
+ * Error convention: functions returning int return 0 (HESS_OK) on success and a negative
+ * hess_status on failure; no exceptions cross this boundary; hess_last_error() gives text.
+ * One context per host thread / per device (reference: one SiftGPU instance per thread per
+ * device, TestWin/MultiThreadSIFT.cpp:90-133).
+ */
+#ifndef HESS_ABI_H
+#define HESS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HESS_ABI_VERSION 1
+
+typedef enum hess_status {
+  HESS_OK = 0,
+  HESS_ERR_ARG = -1,      /* bad argument (null pointer, non-positive size, bad index)   */
+  HESS_ERR_TOO_BIG = -2,  /* image exceeds tex_max_dim and auto_downscale is off
+                             (reference: exit() in PyramidCU.cpp:170-174 -> error return)  */
+  HESS_ERR_DEVICE = -3,   /* HIP runtime error (reference: CheckErrorCUDA -> RunSIFT 0)  */
+  HESS_ERR_NOMEM = -4,    /* allocation failed                                           */
+  HESS_ERR_STATE = -5,    /* call out of order (fetch before run, ...)                   */
+  HESS_ERR_UNSUPPORTED = -6
+} hess_status;
+
+/* Feature types, reference config.h:45-50. */
+enum { HESS_TYPE_DARK_BLOB = 0, HESS_TYPE_BRIGHT_BLOB = 1, HESS_TYPE_SADDLE = 2, HESS_TYPE_NONE = 3 };
+
+/* Truncation methods, reference SiftPyramid.h:73-77 (-tc/-tc1, -tc2, -tc3, -topk). */
+enum { HESS_TRUNC_HIGHEST_0 = 0, HESS_TRUNC_HIGHEST_1 = 1, HESS_TRUNC_LOWEST = 2, HESS_TRUNC_TOPK = 3 };
+
+/* Pixel formats accepted by hess_run_* (the GL enums of SiftGPU::RunSIFT(w,h,data,fmt,type)
+ * are mapped onto these by the C++ class; reference GLTexImage.cpp:918-1036). */
+enum { HESS_FMT_LUM = 1, HESS_FMT_LUM_ALPHA = 2, HESS_FMT_RGB = 3, HESS_FMT_RGBA = 4,
+       HESS_FMT_BGR = 5, HESS_FMT_BGRA = 6 };
+enum { HESS_PIX_U8 = 1, HESS_PIX_U16 = 2, HESS_PIX_F32 = 3 };
+
+/*
+ * Tunables.  Replaces the process-global GlobalParam statics (GlobalUtil.cpp:51-144) and
+ * the SiftParam members (SiftGPU.h:59-86) that the hot path reads.  A zero in a field
+ * marked (0=default) selects the reference default, as SiftParam::ParseSiftParam
+ * (SiftGPU.cpp:491-563) does.
+ */
+typedef struct hess_params {
+  int32_t abi_version;          /* must be HESS_ABI_VERSION                                   */
+  int32_t dog_level_num;        /* -d   (0=default 3)      scales per octave                  */
+  float sigma0;                 /*      (0=default 1.6)                                       */
+  float sigman;                 /*      (0=default 0.5)                                       */
+  float dog_threshold;          /* -t   (0=default 0.02/dog_level_num)                        */
+  float edge_threshold;         /* -e   (0=default 10)                                        */
+  float filter_width_factor;    /* -f   (0=default 4.0)   GlobalUtil.cpp:62                   */
+  float orient_window_factor;   /* -w   (0=default 2.0)   GlobalUtil.cpp:134                  */
+  float orient_gaussian_factor; /*      (0=default 1.5)   GlobalUtil.cpp:135                  */
+  float desc_window_factor;     /* -dw  (0=default 3.0)   GlobalUtil.cpp:63                   */
+  int32_t first_octave;         /* -fo  (>=0; default 0)  SiftGPU.cpp:1166-1175               */
+  int32_t octave_num;           /* -no  (<=0 = no limit)  GlobalUtil.cpp:123                  */
+  int32_t subpixel;             /* -s   (default 1)                                           */
+  int32_t max_orientation;      /* -m   (default 2; clamped to 1..4 by ParseParam)            */
+  int32_t fixed_orientation;    /* -ofix                                                      */
+  int32_t lowe_origin;          /* -loweo                                                     */
+  int32_t half_sift;            /* -half  64-d descriptor, unsigned gradient                  */
+  int32_t compute_descriptors;  /* 0 with -sd                                                 */
+  int32_t normalize;            /* 1 (GlobalUtil::_NormalizedSIFT)                            */
+  int32_t truncate_method;      /* HESS_TRUNC_*                                               */
+  int32_t feature_count_threshold; /* -tc* / -topk value (<=0 = off)                          */
+  int32_t tex_max_dim;          /* -maxd (0=default 3200)                                     */
+  int32_t auto_downscale;       /* -ads                                                       */
+  int32_t verbose;              /* 0 silent                                                   */
+  int32_t reserved[8];
+} hess_params;
+
+/* Binary-identical to SiftGPU::SiftKeypoint (SiftGPU.h:108-116): 24 bytes. */
+typedef struct hess_keypoint {
+  float x, y, s, o;
+  float response;
+  uint16_t level;
+  uint16_t type;
+} hess_keypoint;
+
+/* Stage timers in the order of SiftGPU::_timing[12] (config.h:17-31), milliseconds. */
+enum { HESS_T_LOAD = 0, HESS_T_ALLOC, HESS_T_PYRAMID, HESS_T_DETECT, HESS_T_LIST, HESS_T_ORIENT,
+       HESS_T_MULTI_ORIENT, HESS_T_DOWNLOAD, HESS_T_DESCRIPTOR, HESS_T_VBO, HESS_T_REDUCTION,
+       HESS_T_TOTAL, HESS_T_COUNT };
+
+/* Stage dumps for the parity tests (hess_debug_level `what`). */
+enum { HESS_DBG_GAUSS = 0,  /* Gaussian level, wa*h floats                                   */
+       HESS_DBG_DETH = 1,   /* det-Hessian * sigma^4, wa*h floats                            */
+       HESS_DBG_GOT = 2     /* (|grad|/2, theta) interleaved, 2*wa*h floats, levels 1..dog   */ };
+
+/* One raw detection (before top-K / orientation), for hess_debug_list. 32 bytes. */
+typedef struct hess_rawkey {
+  int32_t level_index;  /* octave*dog_level_num + (level-1)                                  */
+  int32_t col, row;
+  uint32_t packed;      /* half(response)<<16 | 0x4 | type  (key-map pixel .x, ProgramCU.cu:865) */
+  float dx, dy, ds;     /* sub-pixel offsets (ProgramCU.cu:868)                              */
+  uint32_t pad;
+} hess_rawkey;
+
+typedef struct hess_ctx hess_ctx; /* opaque */
+
+/* Fill *p with the reference defaults (all "0=default" fields resolved). */
+void hess_default_params(hess_params* p);
+
+/* Replaces SiftGPU::CreateContextGL/VerifyContextGL -> InitSiftGPU -> new PyramidCU
+ * (SiftGPU.cpp:149-227,1516-1539) and ProgramCU::CheckCudaDevice (ProgramCU.cu:3386-3440).
+ * `device` is the HIP device ordinal.  Returns NULL on failure. */
+hess_ctx* hess_create(int device, const hess_params* params);
+void hess_destroy(hess_ctx* ctx);
+
+/* Replaces PyramidCU::InitPyramid/ResizePyramid/ResizeFeatureStorage (PyramidCU.cpp:113-489)
+ * and SiftGPU::AllocatePyramid: pre-allocates pyramids for `batch` images of w*h so that
+ * hess_run_* does no allocation (grow-only, like the reference). */
+int hess_reserve(hess_ctx* ctx, int width, int height, int batch);
+
+/* Replaces SiftGPU::RunSIFT(w,h,data,fmt,type) -> GLTexInput::SetImageData (CUDA branch,
+ * GLTexImage.cpp:918-1036) -> SiftPyramid::RunSIFT (SiftPyramid.cpp:53-198) for `batch`
+ * independent images of identical size laid out back to back (`image_stride` bytes apart,
+ * rows `pitch` bytes apart).  Host pointer version: pixels are copied to the device. */
+int hess_run_host(hess_ctx* ctx, const void* pixels, int width, int height, int pitch,
+                  size_t image_stride, int batch, int format, int pixtype);
+/* Same, pixels already resident in device memory (HBM) of ctx's device. */
+int hess_run_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
+                    size_t image_stride, int batch, int format, int pixtype);
+
+/* Replaces SiftGPU::GetFeatureNum (SiftGPU.cpp:1551-1554) for image `img` of the last batch. */
+int hess_count(hess_ctx* ctx, int img);
+/* Descriptor length of the last run: 128, 64 (-half) or 0 (-sd). */
+int hess_desc_dim(hess_ctx* ctx);
+/* Replaces SiftGPU::GetFeatureVector -> SiftPyramid::CopyFeatureVector (SiftPyramid.cpp:313-324).
+ * Either output may be NULL.  keys: hess_count() records; desc: hess_count()*hess_desc_dim() floats. */
+int hess_fetch(hess_ctx* ctx, int img, hess_keypoint* keys, float* desc);
+
+/* Pyramid geometry of the last run (PyramidCU.cpp:238-245,274-309): number of octaves, and per
+ * octave the aligned width / height. Arrays must hold >= 32 entries. Returns octave count. */
+int hess_geometry(hess_ctx* ctx, int* widths, int* heights);
+
+/* Parity hooks (no reference counterpart; reference has only the GL viewer's level display). */
+int hess_debug_level(hess_ctx* ctx, int img, int octave, int level, int what, float* out);
+/* Raw detections of image `img` in list order; returns the count (<= cap written). */
+int hess_debug_list(hess_ctx* ctx, int img, hess_rawkey* out, int cap);
+
+/* Stage times of the last hess_run_* in ms, HESS_T_COUNT floats (SiftGPU::_timing, config.h:17-31). */
+const float* hess_timing(hess_ctx* ctx);
+const char* hess_last_error(hess_ctx* ctx);
+
+/* Per-kernel device-time accounting (hipEvents on the context's stream) for bench.py's
+ * roofline leg.  Off by default.  Kernel ids: HESS_K_*. */
+enum { HESS_K_GAUSS = 0, HESS_K_DOWNSAMPLE, HESS_K_HESSIAN, HESS_K_EXTREMA, HESS_K_TOPK,
+       HESS_K_ORIENT, HESS_K_DESCRIPTOR, HESS_K_INPUT, HESS_K_COUNT };
+int hess_profile_enable(hess_ctx* ctx, int on);
+/* Accumulated since the last hess_profile_reset: total ms, launches, algorithmic bytes. */
+int hess_profile_get(hess_ctx* ctx, int kernel, double* ms, long long* launches, double* bytes);
+int hess_profile_reset(hess_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HESS_ABI_H */

@@ -1,0 +1,63 @@
+/*
+ * hess_oracle.h -- CPU ORACLE for the Hessian + SIFT-descriptor hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may link or call this.  The product (hessgpu_amd/, libhessgpu.so,
+ * libsiftgpu.so) never does, and fails loudly when its HIP library is missing.
+ *
+ * PARITY UNPINNED: the reference (sloup/hessgpu) ships no golden vectors, known-answer
+ * tests or fixtures for the Hessian path (doc/evaluation/box.siftgpu
+ * pins only the DoG build), and it cannot be built here (needs nvcc + CUDA runtime +
+ * GLEW/GLUT/DevIL).  This oracle is therefore a plain-C restatement of the reference's
+ * algorithm, checked only against (a) IEEE facts it must satisfy (half conversions vs
+ * numpy.float16, math functions vs libm), and (b) an independently written NumPy
+ * restatement (tests/np_restatement.py).
+ *
+ * Same entry points as include/hess_abi.h with the prefix hess_cpu_.
+ */
+#ifndef HESS_ORACLE_H
+#define HESS_ORACLE_H
+
+#include "../include/hess_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hess_cpu_ctx hess_cpu_ctx;
+
+void hess_cpu_default_params(hess_params* p);
+hess_cpu_ctx* hess_cpu_create(const hess_params* params);
+void hess_cpu_destroy(hess_cpu_ctx* ctx);
+/* Worker threads for the data-parallel loops (OpenMP); 1 = scalar port. */
+void hess_cpu_set_threads(hess_cpu_ctx* ctx, int threads);
+/* Keep every image's pyramid after a run (needed by hess_cpu_debug_level); default on. */
+void hess_cpu_keep_levels(hess_cpu_ctx* ctx, int on);
+
+int hess_cpu_run_host(hess_cpu_ctx* ctx, const void* pixels, int width, int height, int pitch,
+                      size_t image_stride, int batch, int format, int pixtype);
+int hess_cpu_count(hess_cpu_ctx* ctx, int img);
+int hess_cpu_desc_dim(hess_cpu_ctx* ctx);
+int hess_cpu_fetch(hess_cpu_ctx* ctx, int img, hess_keypoint* keys, float* desc);
+int hess_cpu_geometry(hess_cpu_ctx* ctx, int* widths, int* heights);
+int hess_cpu_debug_level(hess_cpu_ctx* ctx, int img, int octave, int level, int what, float* out);
+int hess_cpu_debug_list(hess_cpu_ctx* ctx, int img, hess_rawkey* out, int cap);
+const float* hess_cpu_timing(hess_cpu_ctx* ctx);
+const char* hess_cpu_last_error(hess_cpu_ctx* ctx);
+
+/* Schedule inspection for tests: taps of the blur that produces `level` (level 0 = initial
+ * smoothing) into taps[33]; returns the tap count (0 = no filtering). */
+int hess_cpu_filter_taps(hess_cpu_ctx* ctx, int level, float* taps);
+float hess_cpu_level_sigma(hess_cpu_ctx* ctx, int level);
+
+/* Elementary-function probes for tests/test_oracle_math.py. */
+float hess_cpu_expf(float x);
+float hess_cpu_atan2f(float y, float x);
+void hess_cpu_sincosf(float a, float* s, float* c);
+unsigned short hess_cpu_f2h(float f);
+float hess_cpu_h2f(unsigned short h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
