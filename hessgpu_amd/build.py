@@ -1,0 +1,71 @@
+"""Builds the product's native libraries in-tree with hipcc for gfx950 (MI355X).
+
+  hessgpu_amd/libhessgpu.so   HIP kernels + the C ABI of include/hess_abi.h
+  hessgpu_amd/libsiftgpu.so   SiftGPU C++ plugin surface on top of the C ABI (if its source exists)
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: every fused multiply-add in the kernels
+is an explicit fmaf() (see csrc/hess_devmath.h).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+            "-Wno-unused-function", f"--offload-arch={ARCH}"]
+
+KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_pipeline.hip"]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {cmd[0]} ... {cmd[-1]}")
+    return r
+
+
+def build_all(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "hess_abi.h"))
+    objs, jobs = [], []
+    for src in KERNEL_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src + ".o")
+        objs.append(o)
+        if force or _newer([s] + headers, o):
+            jobs.append([HIPCC] + CXXFLAGS + ["-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(_run, jobs))
+    lib = os.path.join(HERE, "libhessgpu.so")
+    if force or jobs or not os.path.exists(lib):
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+    built = [lib]
+    api_src = os.path.join(CSRC, "siftgpu_api.cpp")
+    if os.path.exists(api_src):
+        api = os.path.join(HERE, "libsiftgpu.so")
+        api_hdr = os.path.join(HERE, "..", "include", "SiftGPU.h")
+        if force or _newer([api_src, api_hdr] + headers, api) or jobs:
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include"),
+                  api_src, "-o", api, "-L", HERE, "-lhessgpu", "-Wl,-rpath,$ORIGIN"])
+        built.append(api)
+    if verbose:
+        print("built:", *built)
+    return built
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

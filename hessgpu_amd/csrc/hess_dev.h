@@ -1,0 +1,152 @@
+// hess_dev.h -- structures shared by the host pipeline and the HIP kernels, and the kernel
+// launcher prototypes.  Vocabulary follows the reference: octave, level, Gaussian (gus),
+// det-Hessian (the reference's "dog" slot), got = (gradient, theta), key, feature list.
+//
+// HBM layout (one context, batch capacity B, SURVEY.md section 8 "Array sizes"):
+//   gauss, deth : float planes  [octave][level 0..dog+1][image][h_o][wa_o]
+//   got         : float2 planes [octave][level 1..dog  ][image][h_o][wa_o]
+//   per image   : row bit-masks / row counts of the extrema scan, raw detection list,
+//                 selected list, feature records, output keypoints + descriptors.
+// All images of a batch have the same size, so one launch covers the batch (blockIdx.z or a
+// flattened row index) and small octaves still fill the chip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hess {
+
+constexpr int kMaxOct = 16;
+constexpr int kMaxDog = 10;
+constexpr int kMaxLev = kMaxDog + 2;
+constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH, ProgramCU.cu:42
+constexpr int kHistBins = 32768;  // abs(half) keys of the top-K selection
+
+struct OctGeom {
+  int wa, h;            // 4-aligned width, height (PyramidCU.cpp:274-309)
+  int plane;            // wa*h
+  int w64;              // mask words per row = ceil(wa/64)
+  long long lvl_off;    // element offset of [octave][0][0] in gauss/deth (units: floats)
+  long long got_off;    // element offset of [octave][1][0] in got (units: float2)
+  int row_base;         // first row index of this octave in the per-image row order
+  int mask_base;        // first mask word of this octave in the per-image mask array
+};
+
+struct Geom {
+  int noct, dog, nlev;  // octaves, detection levels per octave, noct*dog
+  int B;                // batch capacity the planes are laid out for
+  int NR;               // rows per image in list order: dog * sum_o h_o
+  int NM;               // mask words per image
+  OctGeom o[kMaxOct];
+};
+
+struct Taps {
+  int fw;               // number of taps (odd, 5..33)
+  float k[kMaxTaps];
+};
+
+// One raw detection, list order = (level_index, row, col).  Same layout as hess_rawkey.
+struct RawKey {
+  int level_index;
+  int col, row;
+  uint32_t packed;      // half(response)<<16 | 0x4 | type  (ProgramCU.cu:865)
+  float dx, dy, ds;
+  uint32_t pad;
+};
+
+// 16-byte feature record after orientation (ProgramCU.cu:1563-1596).
+struct FRec {
+  uint32_t x, y, z, w;
+};
+
+struct HostKeypoint {   // = SiftGPU::SiftKeypoint (SiftGPU.h:108-116)
+  float x, y, s, o, response;
+  uint16_t level, type;
+};
+
+struct DetectParams {
+  float thr0, thr, edge;  // 0.8*T (or T), T, (e+1)^2/e   (ProgramCU.cu:897,913)
+  int subpixel;
+};
+
+struct LimitParams {
+  int method;     // HESS_TRUNC_*
+  int threshold;  // <=0: off
+};
+
+struct OrientParams {
+  float gaussian_factor, sample_factor;  // 1.5, 1.5*2.0 (ProgramCU.cu:1637-1638)
+  float ln_sigma_step;
+  int num_orientation;  // 0 (-ofix), 1 (-m 1), >1 multi
+  int subpixel, half_sift;
+  float level_sigma[kMaxLev];
+};
+
+struct DescParams {
+  float window_factor;  // 3.0
+  int half_sift, normalize, multi;
+  int lowe_origin;
+  float octave_sigma;   // 2^ds (PyramidCU.cpp:746-748)
+  int dog;
+};
+
+// ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------
+
+// Separable Gaussian, one level for the whole batch: dst = G(taps) * src with replicated
+// borders, tap order and FMA chain of FilterH/FilterV (ProgramCU.cu:117-231).
+// src_u8 != nullptr: source is u8 luminance (value/255.0f, GLTexImage.cpp:828), pitch in bytes.
+void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
+                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps);
+
+// Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
+void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
+                    long long img_stride, int ds, float* dst, int w, int h, int batch);
+
+// Nearest decimation to the next octave (DownsampleKernel, ProgramCU.cu:312-326).
+void launch_downsample(hipStream_t st, const float* src, int sw, int splane, float* dst, int dw,
+                       int dh, int batch);
+
+// det-Hessian * sigma^4 for levels 0..dog+1 of one octave, and (gradient, theta) for levels
+// 1..dog (ComputeHessian_Kernel, ProgramCU.cu:523-595).
+void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gauss, float* deth,
+                    float* got, const float* norms /* device: sigma^4 per level */, int batch);
+
+// Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
+void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
+                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch);
+// Exclusive scan of the row counts per image, level totals, -tc level truncation
+// (GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278).
+void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt,
+                     int* rowoff, int* level_count, int* raw_total, int cap_raw, int* overflow,
+                     int batch);
+// Extrema scan, pass 2: ordered scatter of the detections into the raw list.
+void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
+                            const float* deth, const uint64_t* rowmask, const int* rowoff,
+                            RawKey* raw, int cap_raw, int batch);
+
+// Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
+// the lower list index, order preserved.  sel may alias nothing; when total < K the list is copied.
+void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total,
+                 int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count,
+                 int cap_sel, int batch);
+
+// Orientation (ComputeOrientation_Kernel, ProgramCU.cu:1221-1605): one wavefront per keypoint.
+void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,
+                        const int* list_total, int cap_list, const float* got, FRec* recs,
+                        int* ocount, int batch);
+// Exclusive scan of the per-keypoint orientation counts -> output offsets and feature totals
+// (ReshapeFeatureListCPU, PyramidCU.cpp:720-924; LimitFeatureCount(1)).
+void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi,
+                         const RawKey* list, const int* list_total, int cap_list, const int* ocount,
+                         int* foffset, int* feat_total, int* feat_first, int cap_feat, int* overflow,
+                         int batch);
+// Descriptor + normalisation + host keypoint record (ComputeDescriptor_Kernel /
+// NormalizeDescriptor_Kernel, ProgramCU.cu:1650-2054; keypoint unpack PyramidCU.cpp:866-906).
+void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
+                       const int* list_total, int cap_list, const FRec* recs, const int* ocount,
+                       const int* foffset, const int* feat_total, const int* feat_first,
+                       const float* got, HostKeypoint* keys, float* desc, int cap_feat, int batch);
+
+// Device evaluation of the elementary functions for the parity tests.
+void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);
+
+}  // namespace hess

@@ -1,0 +1,136 @@
+// hess_devmath.h -- device-side elementary functions of the Hessian/SIFT path (gfx950).
+//
+// The reference evaluates expf / atan2 / __sincosf / pow / rsqrt / __fdividef / __float2half_rn
+// with the CUDA math library (ProgramCU.cu:559,865,1297,1359,1413,1698,1741,1989).  This build
+// fixes each of them as an explicit sequence of IEEE binary32 operations (Cephes single-precision
+// algorithms: range reduction + Horner polynomial in fmaf), accurate to <= 2 ulp on the ranges the
+// path uses, so that results do not depend on a vendor math library.  Compile with
+// -ffp-contract=off: every fused multiply-add below is written as fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hess {
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// e^x, x in [-87, 88]; 0 below (weights there are < 1.7e-38).
+__device__ __forceinline__ float dm_expf(float x) {
+  if (x < -87.0f) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float z = r * r;
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, r, 1.3981999507E-3f);
+  p = fmaf(p, r, 8.3334519073E-3f);
+  p = fmaf(p, r, 4.1665795894E-2f);
+  p = fmaf(p, r, 1.6666665459E-1f);
+  p = fmaf(p, r, 5.0000001201E-1f);
+  p = fmaf(p, z, r);
+  p = p + 1.0f;
+  int e = (int)n + 127;
+  return p * u2f((uint32_t)e << 23);
+}
+
+// a^e from ln(a): the orientation kernel's pow(sigma_step, ds) (ProgramCU.cu:1297).
+__device__ __forceinline__ float dm_powf_ln(float ln_a, float e) { return dm_expf(e * ln_a); }
+
+__device__ __forceinline__ float dm_atan01(float t) {
+  float y0 = 0.0f;
+  if (t > 0.4142135623730950f) {
+    y0 = 0.785398163397448309f;
+    t = (t - 1.0f) / (t + 1.0f);
+  }
+  float z = t * t;
+  float p = 8.05374449538e-2f;
+  p = fmaf(p, z, -1.38776856032E-1f);
+  p = fmaf(p, z, 1.99777106478E-1f);
+  p = fmaf(p, z, -3.33329491539E-1f);
+  p = p * z;
+  p = fmaf(p, t, t);
+  return y0 + p;
+}
+
+// atan2(y,x) in [-pi, pi]; (0,0) -> 0.
+__device__ __forceinline__ float dm_atan2f(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = ax > ay ? ax : ay;
+  float mn = ax > ay ? ay : ax;
+  if (mx == 0.0f) return 0.0f;
+  float r = dm_atan01(mn / mx);
+  if (ay > ax) r = 1.57079632679489662f - r;
+  if (x < 0.0f) r = 3.14159265358979324f - r;
+  if (y < 0.0f) r = -r;
+  return r;
+}
+
+__device__ __forceinline__ void dm_sincosf(float a, float* s, float* c) {
+  float k = rintf(a * 0.636619772367581343f);
+  float r = fmaf(k, -1.5703125f, a);
+  r = fmaf(k, -4.837512969970703125e-4f, r);
+  r = fmaf(k, -7.54978995489188216e-8f, r);
+  float z = r * r;
+  float ps = -1.9515295891E-4f;
+  ps = fmaf(ps, z, 8.3321608736E-3f);
+  ps = fmaf(ps, z, -1.6666654611E-1f);
+  ps = ps * z;
+  ps = fmaf(ps, r, r);
+  float pc = 2.443315711809948E-005f;
+  pc = fmaf(pc, z, -1.388731625493765E-003f);
+  pc = fmaf(pc, z, 4.166664568298827E-002f);
+  pc = pc * z;
+  pc = fmaf(pc, z, fmaf(-0.5f, z, 1.0f));
+  int q = ((int)k) & 3;
+  float sv = (q & 1) ? pc : ps;
+  float cv = (q & 1) ? ps : pc;
+  if (q == 1) { cv = -cv; }
+  else if (q == 2) { sv = -sv; cv = -cv; }
+  else if (q == 3) { sv = -sv; }
+  *s = sv;
+  *c = cv;
+}
+
+// binary32 -> binary16 bits, round to nearest even (__float2half_rn, ProgramCU.cu:865).
+__device__ __forceinline__ uint32_t dm_f2h(float f) {
+  uint32_t x = f2u(f);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x > 0x7f800000u) return sign | 0x7e00u;
+  if (x >= 0x477ff000u) return sign | 0x7c00u;
+  if (x >= 0x38800000u) {
+    uint32_t m = x - 0x38000000u;
+    m += 0x00000fffu + ((m >> 13) & 1u);
+    return sign | (m >> 13);
+  }
+  if (x < 0x33000000u) return sign;
+  uint32_t e = x >> 23;
+  uint32_t m = (x & 0x007fffffu) | 0x00800000u;
+  uint32_t shift = 126u - e;
+  uint32_t half_lsb = 1u << shift;
+  uint32_t rem = m & (half_lsb - 1u);
+  uint32_t q = m >> shift;
+  uint32_t halfway = half_lsb >> 1;
+  if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+  return sign | q;
+}
+
+// binary16 bits -> binary32 (exact widening; __half2float / GlobalUtil.cpp:588-621).
+__device__ __forceinline__ float dm_h2f(uint32_t h) {
+  uint32_t sign = (h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu;
+  uint32_t m = h & 0x3ffu;
+  if (e == 0) {
+    if (m == 0) return u2f(sign);
+    int sh = 0;
+    while (!(m & 0x400u)) { m <<= 1; sh++; }
+    m &= 0x3ffu;
+    return u2f(sign | ((uint32_t)(113 - sh) << 23) | (m << 13));
+  }
+  if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+  return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+}  // namespace hess

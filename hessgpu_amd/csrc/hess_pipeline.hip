@@ -1,0 +1,752 @@
+// hess_pipeline.hip -- host side of the C ABI (include/hess_abi.h): context, HBM buffers,
+// sigma schedule, octave geometry and the enqueue order of the hot path on one HIP stream.
+//
+// Replaces the per-image host orchestration of the reference: SiftPyramid::RunSIFT
+// (SiftPyramid.cpp:53-198), PyramidCU::BuildPyramid / DetectKeypointsEX / GenerateFeatureList /
+// SelectTopK / GetFeatureOrientations / ReshapeFeatureListCPU / GetFeatureDescriptors
+// (PyramidCU.cpp:491-553,720-924,1283-1368,1486-1699,1815-1987) and the buffer management of
+// CuTexImage (CuTexImage.cpp).  Differences by design: one batch of equally sized images per
+// call, every stage enqueued without host synchronisation, a single device->host transfer of the
+// counts followed by one of the results; feature-list order is deterministic (level, row, col).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hess_abi.h"
+#include "hess_dev.h"
+
+using namespace hess;
+
+namespace {
+
+struct Schedule {
+  int dog, level_max, level_num, level_ds;
+  float sigma[kMaxLev];        // inter-level blur (SiftGPU.cpp:547-552)
+  float level_sigma[kMaxLev];  // GetLevelSigma (SiftGPU.cpp:1422-1425)
+  float norm[kMaxLev];         // level_sigma^4 as the ComputeHessian wrapper forms it
+  float sigma_step, ln_sigma_step;
+  Taps taps[kMaxLev];          // taps[l] produces level l from level l-1 (l >= 1)
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kernel;
+  double bytes;
+};
+
+}  // namespace
+
+struct hess_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  hess_params p;
+  Schedule sch;
+  // geometry of the current plan
+  bool planned = false;
+  int in_w = 0, in_h = 0;   // caller's image size
+  int ds = 0;               // input decimation (first_octave / auto down-scaling)
+  int img_w = 0, img_h = 0; // after decimation and width truncation
+  Geom g;
+  Taps taps0;               // initial smoothing
+  bool has_taps0 = false;
+  int cap_raw = 0, cap_sel = 0, cap_feat = 0;
+  bool use_topk = false, multi = false;
+  int dim = 0;
+  // device buffers (grow-only, like CuTexImage::InitTexture)
+  DevBuf gauss, deth, got, input_f32, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
+      hist, sel_total, sel_level_count, recs, ocount, foffset, feat_total, feat_first, keys, desc;
+  // host results
+  int batch = 0;
+  std::vector<int> counts;
+  std::vector<size_t> offs;
+  DevBuf h_keys, h_desc, h_small;  // pinned
+  const RawKey* d_list = nullptr;  // list fed to the orientation stage in the last run
+  const int* d_list_total = nullptr;
+  int cap_list = 0;
+  float timing[HESS_T_COUNT];
+  hipEvent_t ev[8];
+  bool have_ev = false;
+  std::string err;
+  // profiling
+  bool prof = false;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> pool;
+  double k_ms[HESS_K_COUNT];
+  long long k_n[HESS_K_COUNT];
+  double k_bytes[HESS_K_COUNT];
+};
+
+namespace {
+
+void set_err(hess_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  c->err = buf;
+  if (c->p.verbose) fprintf(stderr, "hessgpu: %s\n", buf);
+}
+
+#define HIP_TRY(c, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      set_err(c, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;                \
+    }                                                                                     \
+  } while (0)
+
+int ensure(hess_ctx* c, DevBuf& b, size_t bytes, bool pinned_host = false) {
+  if (bytes <= b.bytes) return 0;
+  if (b.p) {
+    if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t want = bytes + bytes / 8;  // slack so slightly larger inputs do not reallocate
+  if (pinned_host) HIP_TRY(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+  else HIP_TRY(c, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return 0;
+}
+
+void release(DevBuf& b, bool pinned_host = false) {
+  if (b.p) { if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+// ---- parameters: GlobalUtil.cpp:51-144 defaults, SiftParam::ParseSiftParam SiftGPU.cpp:491-563 ----
+
+void default_params(hess_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->abi_version = HESS_ABI_VERSION;
+  p->dog_level_num = 3;
+  p->sigma0 = 1.6f;
+  p->sigman = 0.5f;
+  p->dog_threshold = 0.02f / 3;
+  p->edge_threshold = 10.0f;
+  p->filter_width_factor = 4.0f;
+  p->orient_window_factor = 2.0f;
+  p->orient_gaussian_factor = 1.5f;
+  p->desc_window_factor = 3.0f;
+  p->first_octave = 0;
+  p->octave_num = -1;
+  p->subpixel = 1;
+  p->max_orientation = 2;
+  p->compute_descriptors = 1;
+  p->normalize = 1;
+  p->truncate_method = HESS_TRUNC_HIGHEST_0;
+  p->feature_count_threshold = -1;
+  p->tex_max_dim = 3200;
+}
+
+// ProgramCU::CreateFilterKernel, ProgramCU.cu:423-453 (host arithmetic, libm expf).
+void make_taps(const hess_params& p, float sigma, Taps* t) {
+  int sz = (int)ceil(p.filter_width_factor * sigma - 0.5);
+  int width = 2 * sz + 1;
+  if (width > kMaxTaps) { sz = kMaxTaps >> 1; width = kMaxTaps; }
+  else if (width < 5) { sz = 2; width = 5; }
+  float rv = 1.0f / (sigma * sigma), v, ksum = 0;
+  for (int i = -sz; i <= sz; ++i) {
+    t->k[i + sz] = v = expf(-0.5f * i * i * rv);
+    ksum += v;
+  }
+  rv = 1.0f / ksum;
+  for (int i = 0; i < width; i++) t->k[i] *= rv;
+  for (int i = width; i < kMaxTaps; i++) t->k[i] = 0.0f;
+  t->fw = width;
+}
+
+void resolve(hess_ctx* c) {
+  hess_params& p = c->p;
+  if (p.dog_level_num == 0) p.dog_level_num = 3;
+  if (p.sigma0 == 0.0f) p.sigma0 = 1.6f;
+  if (p.sigman == 0.0f) p.sigman = 0.5f;
+  if (p.filter_width_factor == 0.0f) p.filter_width_factor = 4.0f;
+  if (p.orient_window_factor == 0.0f) p.orient_window_factor = 2.0f;
+  if (p.orient_gaussian_factor == 0.0f) p.orient_gaussian_factor = 1.5f;
+  if (p.desc_window_factor == 0.0f) p.desc_window_factor = 3.0f;
+  if (p.tex_max_dim == 0) p.tex_max_dim = 3200;
+  if (p.max_orientation < 1) p.max_orientation = 1;  // SiftGPU.cpp:1047
+  if (p.max_orientation > 4) p.max_orientation = 4;
+  Schedule& s = c->sch;
+  s.dog = p.dog_level_num;
+  s.level_max = s.dog + 1;
+  s.level_num = s.level_max + 1;
+  s.level_ds = s.dog;
+  const float sigmak = powf(2.0f, 1.0f / p.dog_level_num);
+  const float dsigma0 = p.sigma0 * sqrtf(sigmak * sigmak - 1.0f);
+  for (int i = 1; i <= s.level_max; i++) {
+    s.sigma[i - 1] = dsigma0 * powf(sigmak, (float)(i - 1));
+    make_taps(p, s.sigma[i - 1], &s.taps[i]);
+  }
+  for (int l = 0; l <= s.level_max; l++) {
+    s.level_sigma[l] = p.sigma0 * powf(2.0f, (float)l / (float)p.dog_level_num);
+    const float ls = s.level_sigma[l] * 1.0f;  // octaveSigma = 1 (PyramidCU.cpp:1574-1585)
+    const float n2 = ls * ls;                  // passed by DetectKeypointsEX
+    s.norm[l] = n2 * n2;                       // squared again by ProgramCU::ComputeHessian (:592)
+  }
+  if (p.dog_threshold == 0.0f) p.dog_threshold = 0.02f / p.dog_level_num;
+  if (p.edge_threshold == 0.0f) p.edge_threshold = 10.0f;
+  s.sigma_step = powf(2.0f, 1.0f / p.dog_level_num);
+  s.ln_sigma_step = (float)log((double)s.sigma_step);
+}
+
+float initial_smooth_sigma(const hess_ctx* c, int octave_min) {  // SiftGPU.cpp:482-489
+  const float sa = c->p.sigma0 * powf(2.0f, 0.0f / (float)c->p.dog_level_num);
+  const float sb = c->p.sigman / powf(2.0f, (float)octave_min);
+  return (sa > sb + 0.001) ? sqrtf(sa * sa - sb * sb) : 0.0f;
+}
+
+int fmt_channels(int format) {
+  switch (format) {
+    case HESS_FMT_LUM: return 1;
+    case HESS_FMT_LUM_ALPHA: return 2;
+    case HESS_FMT_RGB: case HESS_FMT_BGR: return 3;
+    case HESS_FMT_RGBA: case HESS_FMT_BGRA: return 4;
+  }
+  return 0;
+}
+
+// Geometry: SetImageData (GLTexImage.cpp:932-1033) + InitPyramid/ResizePyramid (PyramidCU.cpp:113-310).
+int plan(hess_ctx* c, int width, int height, int batch) {
+  const hess_params& p = c->p;
+  int ds = 0, ws = width, hs = height;
+  if (p.first_octave > 0) { ds = p.first_octave; ws = width >> ds; hs = height >> ds; }
+  if (ws > p.tex_max_dim || hs > p.tex_max_dim) {
+    if (!p.auto_downscale) {
+      set_err(c, "image %dx%d exceeds max dimension %d (use -ads or -maxd)", ws, hs, p.tex_max_dim);
+      return HESS_ERR_TOO_BIG;
+    }
+    do { ds++; ws >>= 1; hs >>= 1; } while (ws > p.tex_max_dim || hs > p.tex_max_dim);
+  }
+  ws &= ~3;  // TruncateWidthCU
+  if (ws < 4 || hs < 1) { set_err(c, "image too small"); return HESS_ERR_ARG; }
+  const bool same = c->planned && c->in_w == width && c->in_h == height && batch <= c->g.B;
+  if (same) return 0;
+  const int B = (c->planned && c->g.B > batch) ? c->g.B : batch;
+
+  Geom g;
+  memset(&g, 0, sizeof(g));
+  const int input_sz = ws < hs ? ws : hs;
+  int nmax = (int)floor(log((double)input_sz) / log(2.0)) - 3;  // PyramidCU.cpp:242
+  if (nmax < 1) nmax = 1;
+  if (nmax > kMaxOct) nmax = kMaxOct;
+  g.noct = (p.octave_num >= 1 && p.octave_num < nmax) ? p.octave_num : nmax;
+  g.dog = c->sch.dog;
+  g.nlev = g.noct * g.dog;
+  g.B = B;
+  long long lvl = 0, gt = 0;
+  int rows = 0, mw = 0;
+  int w = ws, h = hs;
+  for (int o = 0; o < g.noct; o++) {
+    OctGeom& og = g.o[o];
+    og.wa = ((w + 3) / 4) * 4;
+    og.h = h;
+    og.plane = og.wa * og.h;
+    og.w64 = (og.wa + 63) / 64;
+    og.lvl_off = lvl;
+    og.got_off = gt;
+    og.row_base = rows;
+    og.mask_base = mw;
+    lvl += (long long)c->sch.level_num * B * og.plane;
+    gt += (long long)g.dog * B * og.plane;
+    rows += g.dog * og.h;
+    mw += g.dog * og.h * og.w64;
+    w >>= 1;
+    h >>= 1;
+  }
+  g.NR = rows;
+  g.NM = mw;
+
+  c->use_topk = (p.truncate_method == HESS_TRUNC_TOPK && p.feature_count_threshold > 0);
+  c->multi = (p.max_orientation > 1) && !p.fixed_orientation;  // SiftPyramid.cpp:140
+  c->dim = p.compute_descriptors ? (p.half_sift ? 64 : 128) : 0;
+  long long det_px = gt / B;  // detection pixels per image
+  int cap_raw = (int)(det_px / 32 < 16384 ? 16384 : det_px / 32);
+  if (cap_raw < c->cap_raw) cap_raw = c->cap_raw;
+  int cap_sel = c->use_topk ? p.feature_count_threshold : cap_raw;
+  if (cap_sel > cap_raw) cap_sel = cap_raw;
+  int cap_feat = c->multi ? (c->use_topk ? 4 * cap_sel : cap_sel) : cap_sel;
+  if (cap_feat < c->cap_feat) cap_feat = c->cap_feat;
+
+  int rc;
+  if ((rc = ensure(c, c->gauss, (size_t)lvl * 4))) return rc;
+  if ((rc = ensure(c, c->deth, (size_t)lvl * 4))) return rc;
+  if ((rc = ensure(c, c->got, (size_t)gt * 8))) return rc;
+  if ((rc = ensure(c, c->input_f32, (size_t)B * ws * hs * 4))) return rc;
+  if ((rc = ensure(c, c->rowmask, (size_t)B * g.NM * 8))) return rc;
+  if ((rc = ensure(c, c->rowcnt, (size_t)B * g.NR * 4))) return rc;
+  if ((rc = ensure(c, c->rowoff, (size_t)B * g.NR * 4))) return rc;
+  if ((rc = ensure(c, c->level_count, (size_t)B * g.nlev * 4))) return rc;
+  if ((rc = ensure(c, c->sel_level_count, (size_t)B * g.nlev * 4))) return rc;
+  if ((rc = ensure(c, c->raw_total, (size_t)B * 4))) return rc;
+  if ((rc = ensure(c, c->sel_total, (size_t)B * 4))) return rc;
+  if ((rc = ensure(c, c->feat_total, (size_t)B * 4))) return rc;
+  if ((rc = ensure(c, c->feat_first, (size_t)B * 4))) return rc;
+  if ((rc = ensure(c, c->overflow, 16))) return rc;
+  if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
+  if (c->use_topk) {
+    if ((rc = ensure(c, c->sel, (size_t)B * cap_sel * sizeof(RawKey)))) return rc;
+    if ((rc = ensure(c, c->hist, (size_t)B * kHistBins * 4))) return rc;
+  }
+  if ((rc = ensure(c, c->recs, (size_t)B * cap_sel * sizeof(FRec)))) return rc;
+  if ((rc = ensure(c, c->ocount, (size_t)B * cap_sel * 4))) return rc;
+  if ((rc = ensure(c, c->foffset, (size_t)B * cap_sel * 4))) return rc;
+  if ((rc = ensure(c, c->keys, (size_t)B * cap_feat * sizeof(HostKeypoint)))) return rc;
+  if (c->dim && (rc = ensure(c, c->desc, (size_t)B * cap_feat * c->dim * 4))) return rc;
+  if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 4) * 4, true))) return rc;
+
+  c->g = g;
+  c->ds = ds;
+  c->img_w = ws;
+  c->img_h = hs;
+  c->in_w = width;
+  c->in_h = height;
+  c->cap_raw = cap_raw;
+  c->cap_sel = cap_sel;
+  c->cap_feat = cap_feat;
+  c->planned = true;
+  const float s0 = initial_smooth_sigma(c, ds);
+  c->has_taps0 = s0 > 0.0f;
+  if (c->has_taps0) make_taps(p, s0, &c->taps0);
+  return 0;
+}
+
+// ---- profiling helpers ----
+hipEvent_t get_event(hess_ctx* c) {
+  if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  hess_ctx* c;
+  EventPair ep;
+  bool on;
+  ProfScope(hess_ctx* ctx, int kernel, double bytes) : c(ctx), on(ctx->prof) {
+    if (!on) return;
+    ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes;
+    (void)hipEventRecord(ep.a, c->st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(ep.b, c->st);
+    c->pending.push_back(ep);
+  }
+};
+void drain_profile(hess_ctx* c) {
+  for (auto& ep : c->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+      c->k_ms[ep.kernel] += ms;
+      c->k_n[ep.kernel] += 1;
+      c->k_bytes[ep.kernel] += ep.bytes;
+    }
+    c->pool.push_back(ep.a);
+    c->pool.push_back(ep.b);
+  }
+  c->pending.clear();
+}
+
+// Enqueue the whole path for `batch` images whose pixels are at device address `dev`.
+int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int batch, int format, int pixtype) {
+  const hess_params& p = c->p;
+  const Schedule& s = c->sch;
+  const Geom& g = c->g;
+  hipStream_t st = c->st;
+  float* gauss = (float*)c->gauss.p;
+  float* deth = (float*)c->deth.p;
+  float* got = (float*)c->got.p;
+  auto plane_ptr = [&](float* base, int o, int l) { return base + g.o[o].lvl_off + (long long)l * g.B * g.o[o].plane; };
+
+  (void)hipEventRecord(c->ev[0], st);
+  // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
+  const bool direct_u8 = (format == HESS_FMT_LUM && pixtype == HESS_PIX_U8 && c->ds == 0 && c->has_taps0 &&
+                          (pitch % 4) == 0 && (image_stride % 4) == 0 && ((uintptr_t)dev % 4) == 0);
+  const float* src_f = nullptr;
+  if (!direct_u8) {
+    ProfScope ps(c, HESS_K_INPUT, (double)batch * c->img_w * c->img_h * (4.0 + fmt_channels(format)));
+    launch_convert(st, dev, format, pixtype, pitch, (long long)image_stride, c->ds, (float*)c->input_f32.p,
+                   c->img_w, c->img_h, batch);
+    src_f = (const float*)c->input_f32.p;
+  }
+  for (int o = 0; o < g.noct; o++) {
+    const OctGeom& og = g.o[o];
+    // image b of level l lives at plane_ptr(.., o, l) + b*plane: a batch is contiguous per level
+    if (o == 0) {
+      if (c->has_taps0) {
+        ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (direct_u8 ? 5.0 : 8.0));
+        if (direct_u8)
+          launch_gauss(st, nullptr, (const uint8_t*)dev, pitch, (long long)image_stride, plane_ptr(gauss, 0, 0),
+                       og.wa, og.h, batch, c->taps0);
+        else
+          launch_gauss(st, src_f, nullptr, og.wa, og.plane, plane_ptr(gauss, 0, 0), og.wa, og.h, batch, c->taps0);
+      } else {
+        (void)hipMemcpyAsync(plane_ptr(gauss, 0, 0), src_f, (size_t)batch * og.plane * 4, hipMemcpyDeviceToDevice, st);
+      }
+    } else {
+      ProfScope ps(c, HESS_K_DOWNSAMPLE, (double)batch * og.plane * 8.0);
+      launch_downsample(st, plane_ptr(gauss, o - 1, s.level_ds), g.o[o - 1].wa, g.o[o - 1].plane,
+                        plane_ptr(gauss, o, 0), og.wa, og.h, batch);
+    }
+    for (int l = 1; l <= s.level_max; l++) {
+      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * 8.0);
+      launch_gauss(st, plane_ptr(gauss, o, l - 1), nullptr, og.wa, og.plane, plane_ptr(gauss, o, l), og.wa, og.h,
+                   batch, s.taps[l]);
+    }
+  }
+  (void)hipEventRecord(c->ev[1], st);
+  // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
+  for (int o = 0; o < g.noct; o++) {
+    ProfScope ps(c, HESS_K_HESSIAN, (double)batch * g.o[o].plane * (8.0 * s.level_num + 8.0 * g.dog));
+    launch_hessian(st, g, o, gauss, deth, got, s.norm, batch);
+  }
+  // ---- extrema + ordered list (DetectKeypointsEX part 2 + GenerateFeatureList) ----
+  DetectParams dp;
+  dp.thr = p.dog_threshold;
+  dp.thr0 = (p.subpixel ? 0.8f : 1.0f) * p.dog_threshold;                            // ProgramCU.cu:897
+  dp.edge = (p.edge_threshold + 1) * (p.edge_threshold + 1) / p.edge_threshold;      // ProgramCU.cu:913
+  dp.subpixel = p.subpixel;
+  LimitParams lp;
+  lp.method = p.truncate_method;
+  lp.threshold = p.feature_count_threshold;
+  (void)hipMemsetAsync(c->overflow.p, 0, 16, st);
+  {
+    // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
+    double det_bytes = 0;
+    for (int o = 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
+    ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
+    launch_extrema_mark(st, g, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
+  }
+  (void)hipEventRecord(c->ev[2], st);
+  launch_row_scan(st, g, lp, (const int*)c->rowcnt.p, (int*)c->rowoff.p, (int*)c->level_count.p,
+                  (int*)c->raw_total.p, c->cap_raw, (int*)c->overflow.p, batch);
+  {
+    ProfScope ps(c, HESS_K_EXTREMA, 0.0);
+    launch_extrema_scatter(st, g, dp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowoff.p,
+                           (RawKey*)c->raw.p, c->cap_raw, batch);
+  }
+  (void)hipEventRecord(c->ev[3], st);
+  // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
+  const RawKey* list = (const RawKey*)c->raw.p;
+  const int* list_total = (const int*)c->raw_total.p;
+  int cap_list = c->cap_raw;
+  if (c->use_topk) {
+    ProfScope ps(c, HESS_K_TOPK, 0.0);
+    launch_topk(st, g, p.feature_count_threshold, (const RawKey*)c->raw.p, (const int*)c->raw_total.p, c->cap_raw,
+                (unsigned*)c->hist.p, (RawKey*)c->sel.p, (int*)c->sel_total.p, (int*)c->sel_level_count.p,
+                c->cap_sel, batch);
+    list = (const RawKey*)c->sel.p;
+    list_total = (const int*)c->sel_total.p;
+    cap_list = c->cap_sel;
+  }
+  c->d_list = list;
+  c->d_list_total = list_total;
+  c->cap_list = cap_list;
+  (void)hipEventRecord(c->ev[4], st);
+  // ---- orientation (GetFeatureOrientations) ----
+  OrientParams op;
+  op.gaussian_factor = p.orient_gaussian_factor;
+  op.sample_factor = p.orient_gaussian_factor * p.orient_window_factor;  // ProgramCU.cu:1638
+  op.ln_sigma_step = s.ln_sigma_step;
+  op.num_orientation = p.fixed_orientation ? 0 : p.max_orientation;      // ProgramCU.cu:1639
+  op.subpixel = p.subpixel;
+  op.half_sift = p.half_sift;
+  for (int l = 0; l < kMaxLev; l++) op.level_sigma[l] = l <= s.level_max ? s.level_sigma[l] : 0.0f;
+  {
+    ProfScope ps(c, HESS_K_ORIENT, 0.0);
+    launch_orientation(st, g, op, list, list_total, cap_list, got, (FRec*)c->recs.p, (int*)c->ocount.p, batch);
+  }
+  (void)hipEventRecord(c->ev[5], st);
+  // ---- multi-orientation expansion (ReshapeFeatureListCPU) ----
+  launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
+                      (int*)c->foffset.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
+                      (int*)c->overflow.p + 1, batch);
+  (void)hipEventRecord(c->ev[6], st);
+  // ---- descriptors (GetFeatureDescriptors) ----
+  DescParams dsp;
+  dsp.window_factor = p.desc_window_factor;
+  dsp.half_sift = p.half_sift;
+  dsp.normalize = p.normalize;
+  dsp.multi = c->multi ? 1 : 0;
+  dsp.lowe_origin = p.lowe_origin;
+  dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;  // PyramidCU.cpp:746-748
+  dsp.dog = g.dog;
+  {
+    ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
+    launch_descriptor(st, g, dsp, list, list_total, cap_list, (const FRec*)c->recs.p, (const int*)c->ocount.p,
+                      (const int*)c->foffset.p, (const int*)c->feat_total.p, (const int*)c->feat_first.p, got,
+                      (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, batch);
+  }
+  (void)hipEventRecord(c->ev[7], st);
+  return 0;
+}
+
+int run_device_impl(hess_ctx* c, const void* dev, int width, int height, int pitch, size_t image_stride, int batch,
+                    int format, int pixtype, double* t_load_ms) {
+  int rc = plan(c, width, height, batch);
+  if (rc) return rc;
+  int* hs = (int*)c->h_small.p;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    HIP_TRY(c, hipGetLastError());
+    rc = enqueue(c, dev, pitch, image_stride, batch, format, pixtype);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(hs, c->feat_total.p, (size_t)batch * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(hs + batch, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    const int of_raw = hs[batch], of_feat = hs[batch + 1];
+    if (!of_raw && !of_feat) break;
+    // grow-only reallocation, then run the batch again (reference: SetLevelFeatureNum grows on demand)
+    if (of_raw) c->cap_raw = of_raw + of_raw / 4;
+    if (of_feat) c->cap_feat = of_feat + of_feat / 4;
+    c->planned = false;
+    if (c->p.verbose) fprintf(stderr, "hessgpu: feature storage grown (raw %d, features %d)\n", c->cap_raw, c->cap_feat);
+    rc = plan(c, width, height, batch);
+    if (rc) return rc;
+  }
+  drain_profile(c);
+  // ---- results to host: one transfer of keypoints, one of descriptors per image ----
+  c->batch = batch;
+  c->counts.assign(hs, hs + batch);
+  c->offs.assign(batch + 1, 0);
+  for (int b = 0; b < batch; b++) c->offs[b + 1] = c->offs[b] + (size_t)c->counts[b];
+  const size_t total = c->offs[batch];
+  if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
+  if (c->dim && (rc = ensure(c, c->h_desc, (total ? total : 1) * c->dim * 4, true))) return rc;
+  for (int b = 0; b < batch; b++) {
+    const size_t n = (size_t)c->counts[b];
+    if (!n) continue;
+    HIP_TRY(c, hipMemcpyAsync((HostKeypoint*)c->h_keys.p + c->offs[b], (HostKeypoint*)c->keys.p + (size_t)b * c->cap_feat,
+                              n * sizeof(HostKeypoint), hipMemcpyDeviceToHost, c->st));
+    if (c->dim)
+      HIP_TRY(c, hipMemcpyAsync((float*)c->h_desc.p + c->offs[b] * c->dim,
+                                (float*)c->desc.p + (size_t)b * c->cap_feat * c->dim, n * c->dim * 4,
+                                hipMemcpyDeviceToHost, c->st));
+  }
+  hipEvent_t evd = c->ev[0];  // reuse: record end of download
+  (void)evd;
+  HIP_TRY(c, hipStreamSynchronize(c->st));
+  // stage times from the events of the last enqueue (config.h:17-31 order)
+  memset(c->timing, 0, sizeof(c->timing));
+  auto el = [&](int i, int j) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; };
+  c->timing[HESS_T_LOAD] = t_load_ms ? (float)*t_load_ms : 0.0f;
+  c->timing[HESS_T_PYRAMID] = el(0, 1);
+  c->timing[HESS_T_DETECT] = el(1, 2);
+  c->timing[HESS_T_LIST] = el(2, 3);
+  c->timing[HESS_T_REDUCTION] = el(3, 4);
+  c->timing[HESS_T_ORIENT] = el(4, 5);
+  c->timing[HESS_T_MULTI_ORIENT] = el(5, 6);
+  c->timing[HESS_T_DESCRIPTOR] = el(6, 7);
+  c->timing[HESS_T_TOTAL] = el(0, 7) + c->timing[HESS_T_LOAD];
+  return 0;
+}
+
+}  // namespace
+
+// ================================== C ABI ====================================================
+
+extern "C" {
+
+void hess_default_params(hess_params* p) { if (p) default_params(p); }
+
+hess_ctx* hess_create(int device, const hess_params* params) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    fprintf(stderr, "hessgpu: no usable HIP device %d (found %d)\n", device, ndev);
+    return nullptr;
+  }
+  hess_ctx* c = new (std::nothrow) hess_ctx();
+  if (!c) return nullptr;
+  if (params) c->p = *params; else default_params(&c->p);
+  if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
+      c->p.first_octave < 0) {
+    fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
+    delete c;
+    return nullptr;
+  }
+  c->device = device;
+  resolve(c);
+  memset(c->timing, 0, sizeof(c->timing));
+  memset(c->k_ms, 0, sizeof(c->k_ms));
+  memset(c->k_n, 0, sizeof(c->k_n));
+  memset(c->k_bytes, 0, sizeof(c->k_bytes));
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+    fprintf(stderr, "hessgpu: cannot create stream on device %d\n", device);
+    delete c;
+    return nullptr;
+  }
+  for (int i = 0; i < 8; i++) (void)hipEventCreate(&c->ev[i]);
+  c->have_ev = true;
+  return c;
+}
+
+void hess_destroy(hess_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
+                    &c->level_count, &c->raw_total, &c->overflow, &c->raw, &c->sel, &c->hist, &c->sel_total,
+                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->feat_total, &c->feat_first,
+                    &c->keys, &c->desc};
+  for (DevBuf* b : bufs) release(*b);
+  release(c->h_keys, true);
+  release(c->h_desc, true);
+  release(c->h_small, true);
+  if (c->have_ev) for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
+  for (auto& ep : c->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+int hess_reserve(hess_ctx* c, int width, int height, int batch) {
+  if (!c || width <= 0 || height <= 0 || batch <= 0) return HESS_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return plan(c, width, height, batch);
+}
+
+int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
+                    int batch, int format, int pixtype) {
+  if (!c) return HESS_ERR_ARG;
+  if (!dev_pixels || width <= 0 || height <= 0 || batch <= 0 || pitch <= 0 || !fmt_channels(format) ||
+      pixtype < HESS_PIX_U8 || pixtype > HESS_PIX_F32) {
+    set_err(c, "bad argument");
+    return HESS_ERR_ARG;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  return run_device_impl(c, dev_pixels, width, height, pitch, image_stride, batch, format, pixtype, nullptr);
+}
+
+int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
+                  int format, int pixtype) {
+  if (!c) return HESS_ERR_ARG;
+  if (!pixels || width <= 0 || height <= 0 || batch <= 0 || pitch <= 0 || !fmt_channels(format) ||
+      pixtype < HESS_PIX_U8 || pixtype > HESS_PIX_F32) {
+    set_err(c, "bad argument");
+    return HESS_ERR_ARG;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)(batch - 1) * image_stride + (size_t)height * pitch;
+  int rc = ensure(c, c->stage, bytes + 16);
+  if (rc) return rc;
+  hipEvent_t a = c->ev[0], b = c->ev[1];
+  (void)hipEventRecord(a, c->st);
+  HIP_TRY(c, hipMemcpyAsync(c->stage.p, pixels, bytes, hipMemcpyHostToDevice, c->st));
+  (void)hipEventRecord(b, c->st);
+  HIP_TRY(c, hipStreamSynchronize(c->st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  double load = ms;
+  return run_device_impl(c, c->stage.p, width, height, pitch, image_stride, batch, format, pixtype, &load);
+}
+
+int hess_count(hess_ctx* c, int img) {
+  if (!c || img < 0 || img >= c->batch) return HESS_ERR_ARG;
+  return c->counts[img];
+}
+
+int hess_desc_dim(hess_ctx* c) { return c ? c->dim : HESS_ERR_ARG; }
+
+int hess_fetch(hess_ctx* c, int img, hess_keypoint* keys, float* desc) {
+  if (!c || img < 0 || img >= c->batch) return HESS_ERR_ARG;
+  const size_t n = (size_t)c->counts[img];
+  if (keys && n) memcpy(keys, (HostKeypoint*)c->h_keys.p + c->offs[img], n * sizeof(HostKeypoint));
+  if (desc && c->dim && n) memcpy(desc, (float*)c->h_desc.p + c->offs[img] * c->dim, n * c->dim * 4);
+  return 0;
+}
+
+int hess_geometry(hess_ctx* c, int* widths, int* heights) {
+  if (!c || !c->planned) return HESS_ERR_STATE;
+  for (int o = 0; o < c->g.noct; o++) {
+    if (widths) widths[o] = c->g.o[o].wa;
+    if (heights) heights[o] = c->g.o[o].h;
+  }
+  return c->g.noct;
+}
+
+int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, float* out) {
+  if (!c || !c->planned || !out || img < 0 || img >= c->batch || octave < 0 || octave >= c->g.noct || level < 0 ||
+      level > c->sch.level_max)
+    return HESS_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const OctGeom& og = c->g.o[octave];
+  if (what == HESS_DBG_GAUSS || what == HESS_DBG_DETH) {
+    const float* base = (const float*)(what == HESS_DBG_GAUSS ? c->gauss.p : c->deth.p);
+    const float* src = base + og.lvl_off + ((long long)level * c->g.B + img) * og.plane;
+    HIP_TRY(c, hipMemcpy(out, src, (size_t)og.plane * 4, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (what == HESS_DBG_GOT) {
+    if (level < 1 || level > c->g.dog) return HESS_ERR_ARG;
+    const float* src = (const float*)c->got.p + 2 * (og.got_off + ((long long)(level - 1) * c->g.B + img) * og.plane);
+    HIP_TRY(c, hipMemcpy(out, src, (size_t)og.plane * 8, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  return HESS_ERR_ARG;
+}
+
+int hess_debug_list(hess_ctx* c, int img, hess_rawkey* out, int cap) {
+  if (!c || !c->d_list || img < 0 || img >= c->batch) return HESS_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int n = 0;
+  HIP_TRY(c, hipMemcpy(&n, c->d_list_total + img, 4, hipMemcpyDeviceToHost));
+  const int m = n < cap ? n : cap;
+  static_assert(sizeof(hess_rawkey) == sizeof(RawKey), "raw key layout");
+  if (out && m > 0)
+    HIP_TRY(c, hipMemcpy(out, c->d_list + (size_t)img * c->cap_list, (size_t)m * sizeof(RawKey), hipMemcpyDeviceToHost));
+  return n;
+}
+
+const float* hess_timing(hess_ctx* c) { return c ? c->timing : nullptr; }
+const char* hess_last_error(hess_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int hess_profile_enable(hess_ctx* c, int on) { if (!c) return HESS_ERR_ARG; c->prof = on != 0; return 0; }
+int hess_profile_reset(hess_ctx* c) {
+  if (!c) return HESS_ERR_ARG;
+  memset(c->k_ms, 0, sizeof(c->k_ms));
+  memset(c->k_n, 0, sizeof(c->k_n));
+  memset(c->k_bytes, 0, sizeof(c->k_bytes));
+  return 0;
+}
+int hess_profile_get(hess_ctx* c, int kernel, double* ms, long long* launches, double* bytes) {
+  if (!c || kernel < 0 || kernel >= HESS_K_COUNT) return HESS_ERR_ARG;
+  if (ms) *ms = c->k_ms[kernel];
+  if (launches) *launches = c->k_n[kernel];
+  if (bytes) *bytes = c->k_bytes[kernel];
+  return 0;
+}
+
+// Device evaluation of the elementary functions (tests only; see hess_devmath.h).
+int hess_math_probe(hess_ctx* c, int which, const float* a, const float* b, float* out, int n) {
+  if (!c || !a || !out || n <= 0) return HESS_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(c, hipMalloc(&da, (size_t)n * 4));
+  HIP_TRY(c, hipMalloc(&db, (size_t)n * 4));
+  HIP_TRY(c, hipMalloc(&dout, (size_t)n * 4));
+  HIP_TRY(c, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(db, b ? b : a, (size_t)n * 4, hipMemcpyHostToDevice));
+  launch_math_probe(c->st, which, da, db, dout, n);
+  HIP_TRY(c, hipStreamSynchronize(c->st));
+  HIP_TRY(c, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,542 @@
+// k_detect.hip -- det-Hessian / gradient planes, 3x3x3 extrema scan with sub-pixel refinement,
+// ordered feature-list generation and top-K selection for gfx950 (MI355X).
+//
+// Replaces ComputeHessian_Kernel (ProgramCU.cu:523-595), ComputeKEY_Kernel (:657-882), the 16 B/px
+// key map + ListGen_Kernel second pass (:924-1051), DetectionData* host round trips (:3057-3079)
+// and the bitonic-sort/Blelloch top-K chain (:2205-3051).
+//
+// Structure (no key map, no atomics on the list, no host round trip):
+//   extrema_mark   one wavefront per image row: 64 pixels per step, __ballot -> one 64-bit mask
+//                  word per step and a row count;
+//   row_scan       one workgroup per image: exclusive scan of the row counts in list order
+//                  (level, row) -> row offsets, level totals, -tc level truncation;
+//   extrema_scatter one wavefront per row: lanes whose mask bit is set recompute their keypoint
+//                  and write it at row offset + popcount(lower bits): row-major, deterministic;
+//   topk           15-bit histogram of abs(half(response)) -> exact cut, then one ordered
+//                  compaction pass (ties at the cut resolved towards the lower list index).
+#include "hess_dev.h"
+#include "hess_devmath.h"
+
+namespace hess {
+
+namespace {
+
+// =============================== det-Hessian + gradient ======================================
+
+struct HessArgs {
+  const float* gauss;
+  float* deth;
+  float2* got;
+  int wa, h, plane, B, dog, nlevel, batch;
+  long long lvl_off, got_off;
+  float norm[kMaxLev];  // sigma_l^4 (host passes sigma^2, wrapper squares it: ProgramCU.cu:592)
+};
+
+__device__ __forceinline__ float tex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
+
+// 4 pixels per thread, 16-byte loads/stores.  Neighbour addressing follows the reference's 1-D
+// linear texture: index +-1 wraps across row ends, anything outside [0, wa*h) reads 0.
+__global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
+  const int groups_per_row = a.wa >> 2;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= groups_per_row * a.h) return;
+  const int row = gid / groups_per_row;
+  const int x = (gid - row * groups_per_row) << 2;
+  const int z = blockIdx.y;  // l * batch + b
+  const int l = z / a.batch, b = z - l * a.batch;
+  const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
+  const float* src = a.gauss + poff;
+  const int n = a.plane;
+  const int idx = row * a.wa + x;
+
+  float U[6], M[6], D[6];
+  {
+    float4 m = *reinterpret_cast<const float4*>(src + idx);
+    M[1] = m.x; M[2] = m.y; M[3] = m.z; M[4] = m.w;
+    M[0] = tex1(src, n, idx - 1);
+    M[5] = tex1(src, n, idx + 4);
+    if (row >= 1) {
+      float4 u = *reinterpret_cast<const float4*>(src + idx - a.wa);
+      U[1] = u.x; U[2] = u.y; U[3] = u.z; U[4] = u.w;
+    } else { U[1] = U[2] = U[3] = U[4] = 0.0f; }
+    U[0] = tex1(src, n, idx - a.wa - 1);
+    U[5] = tex1(src, n, idx - a.wa + 4);
+    if (row + 1 < a.h) {
+      float4 d = *reinterpret_cast<const float4*>(src + idx + a.wa);
+      D[1] = d.x; D[2] = d.y; D[3] = d.z; D[4] = d.w;
+    } else { D[1] = D[2] = D[3] = D[4] = 0.0f; }
+    D[0] = tex1(src, n, idx + a.wa - 1);
+    D[5] = tex1(src, n, idx + a.wa + 4);
+  }
+  const float norm = a.norm[l];
+  const bool want_got = (l >= 1 && l <= a.dog);
+  float hv[4];
+  float2 gv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float v11 = U[j], v12 = U[j + 1], v13 = U[j + 2];
+    const float v21 = M[j], v22 = M[j + 1], v23 = M[j + 2];
+    const float v31 = D[j], v32 = D[j + 1], v33 = D[j + 2];
+    const float Lxx = fmaf(-2.0f, v22, v21) + v23;           // ProgramCU.cu:536
+    const float Lyy = fmaf(-2.0f, v22, v12) + v32;           // :537
+    const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;       // :538
+    hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;             // :553
+    if (want_got) {
+      const float dx = v23 - v21, dy = v32 - v12;            // :556-557
+      const float gradient = 0.5f * sqrtf(fmaf(dx, dx, dy * dy));
+      gv[j].x = gradient;
+      gv[j].y = (gradient == 0.0f) ? 0.0f : dm_atan2f(dy, dx);
+    }
+  }
+  *reinterpret_cast<float4*>(a.deth + poff + idx) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+  if (want_got) {
+    float2* g = a.got + a.got_off + ((long long)(l - 1) * a.B + b) * a.plane + idx;
+    *reinterpret_cast<float4*>(g) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
+    *reinterpret_cast<float4*>(g + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
+  }
+}
+
+// =============================== extrema test ================================================
+
+struct KeyVal {
+  uint32_t packed;
+  float dx, dy, ds;
+};
+
+#define HESS_READ_CMP(d0, d1, d2, tex, i)                                        \
+  d0 = tex[(i) - 1]; d1 = tex[(i)]; d2 = tex[(i) + 1];                           \
+  if (response > nmax) {                                                         \
+    nmax = fmaxf(nmax, d0); nmax = fmaxf(nmax, d1); nmax = fmaxf(nmax, d2);      \
+    if ((response < nmax) || (response < 0)) return false;                       \
+  } else {                                                                       \
+    nmin = fminf(nmin, d0); nmin = fminf(nmin, d1); nmin = fminf(nmin, d2);      \
+    if ((response > nmin) || (response > 0)) return false;                       \
+  }
+
+// ComputeKEY_Kernel body for one interior pixel (ProgramCU.cu:725-857).  The comparison macro
+// re-selects its branch per triple with the running nmax exactly as READ_CMP_DOG_DATA does.
+__device__ __forceinline__ bool key_eval(const float* texC, const float* texP, const float* texN,
+                                         const float* texG, int width, int index, const DetectParams& dp,
+                                         KeyVal* out) {
+  float d00, d01, d02, d10, d11, d12, d20, d21, d22;
+  float p00, p01, p02, p10, p11, p12, p20, p21, p22;
+  float n00, n01, n02, n10, n11, n12, n20, n21, n22;
+  float response, nmax, nmin;
+  float dx = 0, dy = 0, ds = 0;
+  bool offset_test_passed = true;
+  const int i0 = index - width, i1 = index, i2 = index + width;
+
+  d11 = response = texC[i1];
+  if (fabsf(response) <= dp.thr0) return false;
+  d10 = texC[i1 - 1];
+  d12 = texC[i1 + 1];
+  nmax = fmaxf(d10, d12);
+  nmin = fminf(d10, d12);
+  if ((response <= nmax) && (response >= nmin)) return false;
+  HESS_READ_CMP(d00, d01, d02, texC, i0);
+  HESS_READ_CMP(d20, d21, d22, texC, i2);
+
+  const float vx2 = response * 2.0f;
+  const float fxx = d10 + d12 - vx2;
+  const float fyy = d01 + d21 - vx2;
+  const float fxy = 0.25f * (d22 + d00 - d20 - d02);
+  const float temp1 = fmaf(fxx, fyy, -(fxy * fxy));
+  const float temp2 = (fxx + fyy) * (fxx + fyy);
+  if ((temp1 <= 0) || (temp2 > dp.edge * temp1)) return false;
+
+  HESS_READ_CMP(p00, p01, p02, texP, i0);
+  HESS_READ_CMP(p10, p11, p12, texP, i1);
+  HESS_READ_CMP(p20, p21, p22, texP, i2);
+  HESS_READ_CMP(n00, n01, n02, texN, i0);
+  HESS_READ_CMP(n10, n11, n12, texN, i1);
+  HESS_READ_CMP(n20, n21, n22, texN, i2);
+  (void)p00; (void)p02; (void)p20; (void)p22; (void)n00; (void)n02; (void)n20; (void)n22;
+
+  if (dp.subpixel) {  // ProgramCU.cu:769-825
+    const float fx = 0.5f * (d12 - d10);
+    const float fy = 0.5f * (d21 - d01);
+    const float fs = 0.5f * (n11 - p11);
+    const float fss = (n11 + p11 - vx2);
+    const float fxs = 0.25f * (n12 + p10 - n10 - p12);
+    const float fys = 0.25f * (n21 + p01 - n01 - p21);
+    float4 A0 = (fxx > 0) ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
+    float4 A1 = (fxy > 0) ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
+    float4 A2 = (fxs > 0) ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
+    const float maxa = fmaxf(fmaxf(A0.x, A1.x), A2.x);
+    if (maxa >= 1e-10) {
+      if (maxa == A1.x) { float4 T = A1; A1 = A0; A0 = T; }
+      else if (maxa == A2.x) { float4 T = A2; A2 = A0; A0 = T; }
+      A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
+      A1.y = fmaf(-A1.x, A0.y, A1.y); A1.z = fmaf(-A1.x, A0.z, A1.z); A1.w = fmaf(-A1.x, A0.w, A1.w);
+      A2.y = fmaf(-A2.x, A0.y, A2.y); A2.z = fmaf(-A2.x, A0.z, A2.z); A2.w = fmaf(-A2.x, A0.w, A2.w);
+      if (fabsf(A2.y) > fabsf(A1.y)) { float4 T = A2; A2 = A1; A1 = T; }
+      if (fabsf(A1.y) >= 1e-10) {
+        A1.z /= A1.y; A1.w /= A1.y;
+        A2.z = fmaf(-A2.y, A1.z, A2.z); A2.w = fmaf(-A2.y, A1.w, A2.w);
+        if (fabsf(A2.z) >= 1e-10) {
+          ds = A2.w / A2.z;
+          dy = fmaf(-ds, A1.z, A1.w);
+          dx = fmaf(-dy, A0.y, fmaf(-ds, A0.z, A0.w));
+          response = fmaf(0.5f, fmaf(ds, fs, fmaf(dx, fx, dy * fy)), d11);
+          offset_test_passed = (fabsf(response) > dp.thr) && (fabsf(ds) < 1.0f) && (fabsf(dx) < 1.0f) &&
+                               (fabsf(dy) < 1.0f);
+        }
+      }
+    }
+  }
+  if (!offset_test_passed) return false;
+  if (out) {
+    uint32_t type;  // ProgramCU.cu:828-851
+    if (response < 0) type = 2u;
+    else {
+      const float g0 = texG[i1 - 1], g1 = texG[i1], g2 = texG[i1 + 1];
+      const float Lxx = fmaf(-2.0f, g1, g0) + g2;
+      type = (Lxx > 0) ? 0u : 1u;
+    }
+    out->packed = (dm_f2h(response) << 16) | 0x4u | type;  // ProgramCU.cu:865
+    out->dx = dx; out->dy = dy; out->ds = ds;
+  }
+  return true;
+}
+
+struct RowTask {
+  int b, o, l, row, li;
+  bool valid;
+};
+
+__device__ __forceinline__ RowTask decode_row(const Geom& g, int wave, int batch) {
+  RowTask t;
+  t.valid = wave < batch * g.NR;
+  t.b = wave / g.NR;
+  int ri = wave - t.b * g.NR;
+  int o = 0;
+  for (int k = 1; k < g.noct; k++)
+    if (g.o[k].row_base <= ri) o = k;
+  t.o = o;
+  int rel = ri - g.o[o].row_base;
+  int lm1 = rel / g.o[o].h;
+  t.l = lm1 + 1;
+  t.row = rel - lm1 * g.o[o].h;
+  t.li = o * g.dog + lm1;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* gauss,
+                                                           const float* deth, uint64_t* rowmask, int* rowcnt,
+                                                           int batch) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  RowTask t = decode_row(g, wave, batch);
+  if (!t.valid) return;
+  const OctGeom& og = g.o[t.o];
+  const long long poff = og.lvl_off + ((long long)t.l * g.B + t.b) * og.plane;
+  const long long lstep = (long long)g.B * og.plane;
+  const float* C = deth + poff;
+  uint64_t* mrow = rowmask + (long long)t.b * g.NM + og.mask_base + ((t.l - 1) * og.h + t.row) * og.w64;
+  const bool row_ok = (t.row > 0) && (t.row < og.h - 1);
+  int cnt = 0;
+  for (int wd = 0; wd < og.w64; wd++) {
+    const int col = wd * 64 + lane;
+    bool flag = false;
+    if (row_ok && col > 0 && col < og.wa - 1)
+      flag = key_eval(C, C - lstep, C + lstep, gauss + poff, og.wa, t.row * og.wa + col, dp, nullptr);
+    const uint64_t m = __ballot(flag);
+    if (lane == 0) mrow[wd] = m;
+    cnt += __popcll(m);
+  }
+  if (lane == 0) rowcnt[wave] = cnt;
+}
+
+__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, const float* gauss,
+                                                              const float* deth, const uint64_t* rowmask,
+                                                              const int* rowoff, RawKey* raw, int cap_raw,
+                                                              int batch) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  RowTask t = decode_row(g, wave, batch);
+  if (!t.valid) return;
+  int base = rowoff[wave];
+  if (base < 0) return;  // level dropped by -tc
+  const OctGeom& og = g.o[t.o];
+  const long long poff = og.lvl_off + ((long long)t.l * g.B + t.b) * og.plane;
+  const long long lstep = (long long)g.B * og.plane;
+  const float* C = deth + poff;
+  const uint64_t* mrow = rowmask + (long long)t.b * g.NM + og.mask_base + ((t.l - 1) * og.h + t.row) * og.w64;
+  RawKey* out = raw + (long long)t.b * cap_raw;
+  for (int wd = 0; wd < og.w64; wd++) {
+    const uint64_t m = mrow[wd];
+    if (m == 0) continue;
+    if ((m >> lane) & 1ull) {
+      const int col = wd * 64 + lane;
+      KeyVal kv;
+      key_eval(C, C - lstep, C + lstep, gauss + poff, og.wa, t.row * og.wa + col, dp, &kv);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < cap_raw) {
+        RawKey rk;
+        rk.level_index = t.li; rk.col = col; rk.row = t.row; rk.packed = kv.packed;
+        rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
+        out[pos] = rk;
+      }
+    }
+    base += __popcll(m);
+  }
+}
+
+// =============================== block scan helpers ==========================================
+
+// Exclusive scan of (a, b) over a 1024-thread workgroup; returns totals through ta/tb.
+__device__ __forceinline__ void block_scan2(int a, int b, int* ea, int* eb, int* ta, int* tb, int* lds /*64 ints*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int na = __shfl_up(ia, d), nb = __shfl_up(ib, d);
+    if (lane >= d) { ia += na; ib += nb; }
+  }
+  __syncthreads();
+  if (lane == 63) { lds[wv] = ia; lds[16 + wv] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0, sa = 0, sb = 0;
+  for (int k = 0; k < 16; k++) {
+    if (k < wv) { oa += lds[k]; ob += lds[16 + k]; }
+    sa += lds[k]; sb += lds[16 + k];
+  }
+  *ea = oa + ia - a; *eb = ob + ib - b; *ta = sa; *tb = sb;
+}
+
+// Level truncation of GenerateFeatureList (-tc2/-tc3 stop adding levels, PyramidCU.cpp:1311-1319)
+// and LimitFeatureCount (SiftPyramid.cpp:201-278).  lc[] is updated in place; returns the total.
+__device__ int apply_level_limits(int* lc, int nlev, const LimitParams& lp, bool generation_stage) {
+  int total = 0;
+  const int thr = lp.threshold;
+  if (generation_stage) {
+    const bool reverse = (lp.method == 1);
+    for (int k = 0; k < nlev; k++) {
+      int li = reverse ? nlev - 1 - k : k;
+      if ((lp.method == 1 || lp.method == 2) && thr > 0 && total > thr) { lc[li] = 0; continue; }
+      total += lc[li];
+    }
+  } else {
+    for (int k = 0; k < nlev; k++) total += lc[k];
+  }
+  if (thr > 0 && lp.method != 3) {
+    if (lp.method == 2) {
+      int i = 0, nf = 0;
+      for (; (nf < thr) && (i < nlev); ++i) nf += lc[i];
+      for (; i < nlev; ++i) lc[i] = 0;
+      if (nf < total) total = nf;
+    } else {
+      int i = 0;
+      while (i < nlev && (total - lc[i]) > thr) { total -= lc[i]; lc[i++] = 0; }
+    }
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, const int* rowcnt, int* rowoff,
+                                                        int* level_count, int* raw_total, int cap_raw,
+                                                        int* overflow) {
+  __shared__ int lc[kMaxOct * kMaxDog];
+  __shared__ int keep[kMaxOct * kMaxDog];
+  __shared__ int lds[64];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int* cnt = rowcnt + (long long)b * g.NR;
+  int* off = rowoff + (long long)b * g.NR;
+  for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  // level totals
+  for (int i = tid; i < g.NR; i += 1024) {
+    int o = 0;
+    for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= i) o = k;
+    int li = o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
+    int c = cnt[i];
+    if (c) atomicAdd(&lc[li], c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int before[kMaxOct * kMaxDog];
+    for (int i = 0; i < g.nlev; i++) before[i] = lc[i];
+    int total = apply_level_limits(lc, g.nlev, lp, true);
+    for (int i = 0; i < g.nlev; i++) {
+      keep[i] = (lc[i] == before[i]);  // a level is either kept whole or dropped
+      level_count[b * g.nlev + i] = lc[i];
+    }
+    raw_total[b] = total < cap_raw ? total : cap_raw;
+    if (total > cap_raw) atomicMax(overflow, total);
+  }
+  __syncthreads();
+  // ordered exclusive scan of the kept rows
+  for (int base = 0; base < g.NR; base += 1024) {
+    int i = base + tid;
+    int c = 0, kp = 1;
+    if (i < g.NR) {
+      int o = 0;
+      for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= i) o = k;
+      int li = o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
+      kp = keep[li];
+      c = kp ? cnt[i] : 0;
+    }
+    int e, e2, tot, tot2;
+    block_scan2(c, 0, &e, &e2, &tot, &tot2, lds);
+    const int cbase = carry;
+    if (i < g.NR) off[i] = kp ? cbase + e : -1;
+    __syncthreads();
+    if (tid == 0) carry = cbase + tot;
+    __syncthreads();
+  }
+}
+
+// =============================== top-K =======================================================
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(int K, const RawKey* raw, const int* raw_total, int cap_raw,
+                                                        unsigned* hist) {
+  const int b = blockIdx.y;
+  const int n = raw_total[b];
+  if (n < K) return;  // SelectTopK is skipped when fewer than K detections (PyramidCU.cpp:1886)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = (raw[(long long)b * cap_raw + i].packed >> 16) & 0x7fffu;  // abs(half)
+  atomicAdd(&hist[(long long)b * kHistBins + key], 1u);
+}
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const RawKey* raw, const int* raw_total,
+                                                           int cap_raw, const unsigned* hist, RawKey* sel,
+                                                           int* sel_total, int* sel_level_count, int cap_sel) {
+  __shared__ int lds[64];
+  __shared__ int lc[kMaxOct * kMaxDog];
+  __shared__ int s_cut, s_need, s_ties, s_kept;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = raw_total[b];
+  const RawKey* in = raw + (long long)b * cap_raw;
+  RawKey* out = sel + (long long)b * cap_sel;
+  for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
+  if (tid == 0) { s_cut = -1; s_need = 0; s_ties = 0; s_kept = 0; }
+  __syncthreads();
+  if (n >= K) {
+    // thread t owns bins [32t, 32t+32); threads are scanned from the high end
+    const unsigned* h = hist + (long long)b * kHistBins;
+    int mine = 0;
+    for (int k = 0; k < 32; k++) mine += (int)h[tid * 32 + k];
+    // suffix sum over threads = exclusive prefix over the reversed order
+    int e, e2, tot, tot2;
+    // reverse: thread r = 1023 - tid contributes in scan position tid
+    __shared__ int rev[1024];
+    rev[1023 - tid] = mine;
+    __syncthreads();
+    block_scan2(rev[tid], 0, &e, &e2, &tot, &tot2, lds);
+    // scan position tid corresponds to bins thread (1023 - tid); e = count in strictly higher bins
+    const int owner = 1023 - tid;
+    const int above = e, incl = e + rev[tid];
+    if (above < K && incl >= K) {
+      int acc = above;
+      for (int k = 31; k >= 0; k--) {
+        int c = (int)h[owner * 32 + k];
+        if (acc + c >= K) { s_cut = owner * 32 + k; s_need = K - acc; break; }
+        acc += c;
+      }
+    }
+    __syncthreads();
+  }
+  const int cut = s_cut, need = s_need;
+  // ordered compaction: keep key > cut, and the first `need` entries with key == cut
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    int keep = 0, tie = 0;
+    RawKey rk;
+    if (i < n) {
+      rk = in[i];
+      if (cut < 0) keep = 1;
+      else {
+        const int key = (int)((rk.packed >> 16) & 0x7fffu);
+        if (key > cut) keep = 1;
+        else if (key == cut) tie = 1;
+      }
+    }
+    int etie, ekeep0, ttie, tkeep0;
+    block_scan2(tie, 0, &etie, &ekeep0, &ttie, &tkeep0, lds);
+    if (tie && (s_ties + etie) < need) keep = 1;
+    int ekeep, edummy, tkeep, tdummy;
+    block_scan2(keep, 0, &ekeep, &edummy, &tkeep, &tdummy, lds);
+    if (keep) {
+      const int pos = s_kept + ekeep;
+      if (pos < cap_sel) out[pos] = rk;
+      atomicAdd(&lc[rk.level_index], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { s_ties += ttie; s_kept += tkeep; }
+    __syncthreads();
+  }
+  if (tid == 0) sel_total[b] = s_kept < cap_sel ? s_kept : cap_sel;
+  for (int i = tid; i < g.nlev; i += 1024) sel_level_count[b * g.nlev + i] = lc[i];
+}
+
+// =============================== math probe (parity tests) ===================================
+__global__ void math_probe_kernel(int which, const float* a, const float* b, float* out, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = 0.0f;
+  switch (which) {
+    case 0: r = dm_expf(a[i]); break;
+    case 1: r = dm_atan2f(a[i], b[i]); break;
+    case 2: { float s, c; dm_sincosf(a[i], &s, &c); r = s; break; }
+    case 3: { float s, c; dm_sincosf(a[i], &s, &c); r = c; break; }
+    case 4: r = (float)dm_f2h(a[i]); break;
+    case 5: r = dm_h2f((uint32_t)a[i]); break;
+    case 6: r = a[i] / b[i]; break;
+    case 7: r = sqrtf(a[i]); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+}  // namespace
+
+void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gauss, float* deth, float* got,
+                    const float* norms, int batch) {
+  const OctGeom& og = g.o[octave];
+  HessArgs a;
+  a.gauss = gauss; a.deth = deth; a.got = reinterpret_cast<float2*>(got);
+  a.wa = og.wa; a.h = og.h; a.plane = og.plane; a.B = g.B; a.dog = g.dog; a.nlevel = g.dog + 2;
+  a.batch = batch; a.lvl_off = og.lvl_off; a.got_off = og.got_off;
+  for (int l = 0; l < g.dog + 2; l++) a.norm[l] = norms[l];
+  const int groups = (og.wa >> 2) * og.h;
+  hipLaunchKernelGGL(hessian_kernel, dim3((groups + 255) / 256, (g.dog + 2) * batch), dim3(256), 0, st, a);
+}
+
+void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
+                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
+  const long long waves = (long long)batch * g.NR;
+  hipLaunchKernelGGL(extrema_mark_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, dp, gauss, deth,
+                     rowmask, rowcnt, batch);
+}
+
+void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt, int* rowoff,
+                     int* level_count, int* raw_total, int cap_raw, int* overflow, int batch) {
+  hipLaunchKernelGGL(row_scan_kernel, dim3(batch), dim3(1024), 0, st, g, lp, rowcnt, rowoff, level_count,
+                     raw_total, cap_raw, overflow);
+}
+
+void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
+                            const float* deth, const uint64_t* rowmask, const int* rowoff, RawKey* raw,
+                            int cap_raw, int batch) {
+  const long long waves = (long long)batch * g.NR;
+  hipLaunchKernelGGL(extrema_scatter_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, dp, gauss,
+                     deth, rowmask, rowoff, raw, cap_raw, batch);
+}
+
+void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
+                 unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch) {
+  hipMemsetAsync(hist, 0, (size_t)batch * kHistBins * sizeof(unsigned), st);
+  hipLaunchKernelGGL(topk_hist_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, K, raw, raw_total,
+                     cap_raw, hist);
+  hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist, sel,
+                     sel_total, sel_level_count, cap_sel);
+}
+
+void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n) {
+  hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, which, a, b, out, n);
+}
+
+}  // namespace hess

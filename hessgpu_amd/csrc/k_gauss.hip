@@ -1,0 +1,242 @@
+// k_gauss.hip -- Gaussian scale-space kernels for gfx950 (MI355X).
+//
+// Replaces FilterH<FW>/FilterV<FW> (two global passes through a scratch buffer, ProgramCU.cu:117-231,
+// 455-512), DownsampleKernel (ProgramCU.cu:312-326) and the host-side pixel conversion
+// (GLTexImage.cpp:802-916).  HBM-bound: 4 B read + 4 B written per pixel and level.
+//
+// gauss_kernel: one workgroup (256 threads = 4 wavefronts) produces a 64x32 tile of one level.
+//   stage 1  source rows [y0-R, y0+32+R) x cols [x0-R4, x0+64+R4) -> LDS `s`, 16-byte global loads,
+//            borders replicated exactly as the reference clamps its fetch index;
+//   stage 2  horizontal pass LDS->LDS: a thread produces 8 adjacent outputs from a register window
+//            (ds_read_b128, row stride = 4 mod 8 dwords: conflict-free);
+//   stage 3  vertical pass LDS->HBM: a thread produces 4 rows x 2 columns (ds_read_b64, 8-byte
+//            coalesced stores, 512 contiguous bytes per wavefront).
+// Per output the taps are accumulated in the reference's order: v = 0; v = fma(x_i, k_i, v), i=0..FW-1.
+#include "hess_dev.h"
+
+namespace hess {
+
+namespace {
+
+constexpr int TW = 64, TH = 32, NT = 256;
+
+struct GaussArgs {
+  const float* src;
+  const uint8_t* src_u8;
+  long long src_pitch;       // elements (float) or bytes (u8) between source rows
+  long long src_img_stride;  // same unit, between images
+  float* dst;                // [batch][h][w]
+  int w, h;
+  Taps taps;
+};
+
+template <int R, bool U8>
+__global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
+  constexpr int FW = 2 * R + 1;
+  constexpr int R4 = (R + 3) & ~3;
+  constexpr int OFF = R4 - R;
+  constexpr int SW = TW + 2 * R4;
+  constexpr int SWP = SW + 4;          // SW % 8 == 0 -> row stride = 4 (mod 8) dwords
+  constexpr int ROWS = TH + 2 * R;
+  constexpr int TWP = TW + 4;
+  constexpr int NG = SW / 4;           // 16-byte groups per staged row
+  constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
+
+  __shared__ __attribute__((aligned(16))) float s[ROWS * SWP];
+  __shared__ __attribute__((aligned(16))) float t[ROWS * TWP];
+
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int w = a.w, h = a.h;
+  const long long img = blockIdx.z;
+
+  // ---- stage 1: global -> LDS, replicate borders (ProgramCU.cu:138, :201) ----
+  for (int g = tid; g < ROWS * NG; g += NT) {
+    int r = g / NG, gx = g - r * NG;
+    int y = y0 - R + r;
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    int x = x0 - R4 + gx * 4;
+    float4 v;
+    if (U8) {
+      const uint8_t* row = a.src_u8 + img * a.src_img_stride + (long long)y * a.src_pitch;
+      if (x >= 0 && x < w) {
+        uchar4 b = *reinterpret_cast<const uchar4*>(row + x);
+        v.x = (float)b.x / 255.0f; v.y = (float)b.y / 255.0f;   // GLTexImage.cpp:828
+        v.z = (float)b.z / 255.0f; v.w = (float)b.w / 255.0f;
+      } else {
+        float e = (float)row[x < 0 ? 0 : w - 1] / 255.0f;
+        v = make_float4(e, e, e, e);
+      }
+    } else {
+      const float* row = a.src + img * a.src_img_stride + (long long)y * a.src_pitch;
+      if (x >= 0 && x < w) {
+        v = *reinterpret_cast<const float4*>(row + x);
+      } else {
+        float e = row[x < 0 ? 0 : w - 1];
+        v = make_float4(e, e, e, e);
+      }
+    }
+    *reinterpret_cast<float4*>(&s[r * SWP + gx * 4]) = v;
+  }
+  __syncthreads();
+
+  // ---- stage 2: horizontal pass, LDS -> LDS ----
+  for (int task = tid; task < ROWS * (TW / 8); task += NT) {
+    int r = task >> 3, xb = (task & 7) * 8;
+    float win[NV * 4];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      float4 q = *reinterpret_cast<const float4*>(&s[r * SWP + xb + 4 * i]);
+      win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < FW; i++) {
+      const float ki = a.taps.k[i];
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[j] = fmaf(win[OFF + j + i], ki, acc[j]);  // ProgramCU.cu:152
+    }
+    *reinterpret_cast<float4*>(&t[r * TWP + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(&t[r * TWP + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  __syncthreads();
+
+  // ---- stage 3: vertical pass, LDS -> HBM ----
+  {
+    const int cg = tid & 31, rg = tid >> 5;
+    float2 col[4 + 2 * R];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * R; i++)
+      col[i] = *reinterpret_cast<const float2*>(&t[(rg * 4 + i) * TWP + cg * 2]);
+    float2 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < FW; i++) {
+      const float ki = a.taps.k[i];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[j].x = fmaf(col[j + i].x, ki, acc[j].x);  // ProgramCU.cu:226
+        acc[j].y = fmaf(col[j + i].y, ki, acc[j].y);
+      }
+    }
+    const int x = x0 + cg * 2;
+    if (x < w) {
+      float* d = a.dst + img * (long long)w * h;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int y = y0 + rg * 4 + j;
+        if (y < h) *reinterpret_cast<float2*>(&d[(long long)y * w + x]) = acc[j];
+      }
+    }
+  }
+}
+
+template <int R>
+void launch_r(hipStream_t st, const GaussArgs& a, int batch) {
+  dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH, batch);
+  if (a.src_u8)
+    hipLaunchKernelGGL((gauss_kernel<R, true>), grid, dim3(NT), 0, st, a);
+  else
+    hipLaunchKernelGGL((gauss_kernel<R, false>), grid, dim3(NT), 0, st, a);
+}
+
+// ---- input conversion (GLTexImage.cpp:802-916): any format/type -> float luminance ----
+struct ConvArgs {
+  const uint8_t* src;
+  long long pitch, img_stride;  // bytes
+  int format, pixtype, ds;
+  float* dst;
+  int w, h;
+};
+
+__device__ __forceinline__ float conv_pixel(const uint8_t* p, int format, int pixtype) {
+  const bool lum = (format == 1 || format == 2);
+  if (pixtype == 3) {
+    const float* f = reinterpret_cast<const float*>(p);
+    if (lum) return f[0];
+    // host arithmetic in the reference: separate multiplies and adds, left to right
+    if (format == 3 || format == 4) return __fadd_rn(__fadd_rn(__fmul_rn(0.299f, f[0]), __fmul_rn(0.587f, f[1])), __fmul_rn(0.114f, f[2]));
+    return __fadd_rn(__fadd_rn(__fmul_rn(0.114f, f[0]), __fmul_rn(0.587f, f[1])), __fmul_rn(0.299f, f[2]));
+  }
+  unsigned v0, v1 = 0, v2 = 0;
+  float factor;
+  if (pixtype == 1) {
+    v0 = p[0]; if (!lum) { v1 = p[1]; v2 = p[2]; }
+    factor = 255.0f;
+  } else {
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
+    v0 = q[0]; if (!lum) { v1 = q[1]; v2 = q[2]; }
+    factor = 65535.0f;
+  }
+  if (lum) return (float)(int)v0 / factor;
+  if (format == 3 || format == 4) return (float)(int32_t)(19595u * v0 + 38470u * v1 + 7471u * v2) / (65535.0f * factor);
+  return (float)(int32_t)(7471u * v0 + 38470u * v1 + 19595u * v2) / (65535.0f * factor);
+}
+
+__global__ __launch_bounds__(256) void convert_kernel(ConvArgs a) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= a.w) return;
+  int nch = (a.format == 1) ? 1 : (a.format == 2 ? 2 : ((a.format == 3 || a.format == 5) ? 3 : 4));
+  int bpc = a.pixtype == 1 ? 1 : (a.pixtype == 2 ? 2 : 4);
+  int step = 1 << a.ds;
+  const uint8_t* p = a.src + (long long)blockIdx.z * a.img_stride + (long long)(y * step) * a.pitch +
+                     (long long)(x * step) * nch * bpc;
+  a.dst[((long long)blockIdx.z * a.h + y) * a.w + x] = conv_pixel(p, a.format, a.pixtype);
+}
+
+// ---- DownsampleKernel<1>, ProgramCU.cu:312-326: dst(x,y) = src(min(2x, sw-1), 2y) ----
+__global__ __launch_bounds__(256) void downsample_kernel(const float* src, int sw, int splane, float* dst,
+                                                         int dw, int dh) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= dw) return;
+  int sc = min(x << 1, sw - 1);
+  dst[((long long)blockIdx.z * dh + y) * dw + x] = src[(long long)blockIdx.z * splane + (long long)(y << 1) * sw + sc];
+}
+
+}  // namespace
+
+void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
+                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps) {
+  GaussArgs a;
+  a.src = src; a.src_u8 = src_u8; a.src_pitch = src_pitch; a.src_img_stride = src_img_stride;
+  a.dst = dst; a.w = wa; a.h = h; a.taps = taps;
+  switch (taps.fw >> 1) {
+    case 2: launch_r<2>(st, a, batch); break;
+    case 3: launch_r<3>(st, a, batch); break;
+    case 4: launch_r<4>(st, a, batch); break;
+    case 5: launch_r<5>(st, a, batch); break;
+    case 6: launch_r<6>(st, a, batch); break;
+    case 7: launch_r<7>(st, a, batch); break;
+    case 8: launch_r<8>(st, a, batch); break;
+    case 9: launch_r<9>(st, a, batch); break;
+    case 10: launch_r<10>(st, a, batch); break;
+    case 11: launch_r<11>(st, a, batch); break;
+    case 12: launch_r<12>(st, a, batch); break;
+    case 13: launch_r<13>(st, a, batch); break;
+    case 14: launch_r<14>(st, a, batch); break;
+    case 15: launch_r<15>(st, a, batch); break;
+    case 16: launch_r<16>(st, a, batch); break;
+    default: break;
+  }
+}
+
+void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
+                    long long img_stride, int ds, float* dst, int w, int h, int batch) {
+  ConvArgs a;
+  a.src = (const uint8_t*)src; a.pitch = pitch; a.img_stride = img_stride;
+  a.format = format; a.pixtype = pixtype; a.ds = ds; a.dst = dst; a.w = w; a.h = h;
+  hipLaunchKernelGGL(convert_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, st, a);
+}
+
+void launch_downsample(hipStream_t st, const float* src, int sw, int splane, float* dst, int dw, int dh,
+                       int batch) {
+  hipLaunchKernelGGL(downsample_kernel, dim3((dw + 255) / 256, dh, batch), dim3(256), 0, st, src, sw, splane,
+                     dst, dw, dh);
+}
+
+}  // namespace hess

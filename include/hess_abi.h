@@ -167,6 +167,10 @@ int hess_profile_enable(hess_ctx* ctx, int on);
 int hess_profile_get(hess_ctx* ctx, int kernel, double* ms, long long* launches, double* bytes);
 int hess_profile_reset(hess_ctx* ctx);
 
+/* Test hook: evaluate one of the device's elementary functions (hess_devmath.h) on n inputs.
+ * which: 0 exp(a) 1 atan2(a,b) 2 sin(a) 3 cos(a) 4 float->half bits 5 half bits->float 6 a/b 7 sqrt(a). */
+int hess_math_probe(hess_ctx* ctx, int which, const float* a, const float* b, float* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

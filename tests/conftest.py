@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory():
+    """Factory for product contexts; skips nothing: on a GPU box a missing library is a failure."""
+    import hessgpu_amd
+
+    made = []
+
+    def make(**overrides):
+        c = hessgpu_amd.HessContext(0, **overrides)
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()

@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path (through the C ABI, libhessgpu.so) against the CPU oracle on the same
+inputs.  Bar: bit-exact for every stage -- pyramid planes, det-Hessian, gradient/theta, the raw
+detection list (integer positions, packed half response, offsets), keypoints and descriptors --
+because both sides evaluate the same IEEE binary32 operation sequences (DESIGN.md "Arithmetic
+model").  The north star's tolerance for descriptors/keypoints is 1e-4; the tests assert 0 first
+and report the max deviation if that ever fails.
+"""
+import numpy as np
+import pytest
+
+import fixtures
+from hessgpu_amd import _abi
+from oracle_lib import OracleSession
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: "keypoints/descriptors matching reference within 1e-4"
+
+
+def _assert_same_features(gk, gd, ok, od, what):
+    assert len(gk) == len(ok), f"{what}: feature count {len(gk)} != oracle {len(ok)}"
+    assert np.array_equal(gk["level"], ok["level"]) and np.array_equal(gk["type"], ok["type"]), f"{what}: level/type"
+    for f in ("x", "y", "s", "o", "response"):
+        if not np.array_equal(gk[f], ok[f]):
+            d = np.max(np.abs(gk[f].astype(np.float64) - ok[f].astype(np.float64)))
+            assert d <= TOL, f"{what}: keypoint field {f} max abs diff {d}"
+            pytest.fail(f"{what}: keypoint field {f} within 1e-4 (max {d}) but not bit-exact")
+    if od.size:
+        if not np.array_equal(gd.view(np.uint32), od.view(np.uint32)):
+            d = np.nanmax(np.abs(gd.astype(np.float64) - od.astype(np.float64)))
+            bad = np.sum(np.any(gd.view(np.uint32) != od.view(np.uint32), axis=1))
+            assert d <= TOL, f"{what}: descriptors max abs diff {d} ({bad} rows differ)"
+            pytest.fail(f"{what}: descriptors within 1e-4 (max {d}, {bad} rows) but not bit-exact")
+
+
+def _compare_all(g, o, imgs, what, stages=True):
+    ng = g.run(imgs)
+    no = o.run(imgs)
+    assert g.geometry() == o.geometry()
+    if stages:
+        nlev = o.params.dog_level_num + 2
+        for b in range(len(no)):
+            for oc in range(len(o.geometry())):
+                for l in range(nlev):
+                    a, r = g.level(b, oc, l, _abi.DBG_GAUSS), o.level(b, oc, l, _abi.DBG_GAUSS)
+                    assert np.array_equal(a.view(np.uint32), r.view(np.uint32)), \
+                        f"{what}: gauss img {b} oct {oc} lvl {l}: {np.sum(a != r)} px differ, max {np.max(np.abs(a - r))}"
+                for l in range(nlev):
+                    a, r = g.level(b, oc, l, _abi.DBG_DETH), o.level(b, oc, l, _abi.DBG_DETH)
+                    assert np.array_equal(a.view(np.uint32), r.view(np.uint32)), \
+                        f"{what}: det-H img {b} oct {oc} lvl {l}: {np.sum(a != r)} px differ, max {np.max(np.abs(a - r))}"
+                for l in range(1, nlev - 1):
+                    a, r = g.level(b, oc, l, _abi.DBG_GOT), o.level(b, oc, l, _abi.DBG_GOT)
+                    assert np.array_equal(a.view(np.uint32), r.view(np.uint32)), \
+                        f"{what}: grad/theta img {b} oct {oc} lvl {l}: {np.sum(a != r)} values differ"
+    for b in range(len(no)):
+        gl, ol = g.rawlist(b), o.rawlist(b)
+        assert len(gl) == len(ol), f"{what}: img {b} list length {len(gl)} != {len(ol)}"
+        assert gl.tobytes() == ol.tobytes(), f"{what}: img {b} detection list differs"
+    assert ng == no, f"{what}: feature counts {ng} != {no}"
+    for b in range(len(no)):
+        gk, gd = g.fetch(b)
+        ok, od = o.fetch(b)
+        _assert_same_features(gk, gd, ok, od, f"{what} img {b}")
+    return no
+
+
+def test_math_functions_bit_exact(gpu_ctx_factory):
+    import ctypes as C
+    from oracle_lib import lib as olib
+
+    g = gpu_ctx_factory()
+    L = olib()
+    rng = np.random.RandomState(7)
+    x = np.concatenate([-rng.rand(20000) * 90.0, [0.0, -87.0, -87.5, -1e-8]]).astype(np.float32)
+    got = g.math_probe(0, x)
+    ref = np.array([L.hess_cpu_expf(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    a = (rng.randn(20000) * 0.3).astype(np.float32)
+    b = (rng.randn(20000) * 0.3).astype(np.float32)
+    a[:4] = [0, 0, 1, -1]; b[:4] = [0, 1, 0, 0]
+    got = g.math_probe(1, a, b)
+    ref = np.array([L.hess_cpu_atan2f(float(p), float(q)) for p, q in zip(a, b)], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    ang = (rng.rand(20000) * 2 * np.pi).astype(np.float32)
+    s, c = g.math_probe(2, ang), g.math_probe(3, ang)
+    rs, rc = np.zeros_like(ang), np.zeros_like(ang)
+    fs, fc = C.c_float(), C.c_float()
+    for i, v in enumerate(ang):
+        L.hess_cpu_sincosf(float(v), C.byref(fs), C.byref(fc))
+        rs[i], rc[i] = fs.value, fc.value
+    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)) and np.array_equal(c.view(np.uint32), rc.view(np.uint32))
+    v = np.concatenate([rng.randn(20000) * 0.05, rng.randn(2000) * 1e-6, [0, 65504, 65519.9, 65520, 1e-8, 6e-8]]).astype(np.float32)
+    h = g.math_probe(4, v)
+    assert np.array_equal(h.astype(np.uint16), v.astype(np.float16).view(np.uint16))
+    # IEEE division and square root on the device (u8/255 conversion, Gaussian elimination, gradient)
+    num, den = rng.rand(20000).astype(np.float32), (rng.rand(20000) + 0.1).astype(np.float32)
+    assert np.array_equal(g.math_probe(6, num, den), num / den)
+    assert np.array_equal(g.math_probe(7, num), np.sqrt(num))
+
+
+def test_parity_640_rgb_all_stages(gpu_ctx_factory):
+    img = fixtures.load_rgb("640-1.jpg")
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8)
+    n = _compare_all(g, o, img[None], "640-1.jpg defaults")
+    assert n[0] > 100
+
+
+def test_parity_list640_sequence(gpu_ctx_factory):
+    """BASELINE.json configs[2]: data/list640.txt processed on one instance, descriptors checked."""
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8, keep_levels=False)
+    for name in fixtures.list640():
+        img = fixtures.load_rgb(name)
+        _compare_all(g, o, img[None], name, stages=False)
+
+
+def test_parity_batch_of_images(gpu_ctx_factory):
+    """The five 640x480 images as ONE batch (batch dimension of every kernel)."""
+    imgs = np.stack([fixtures.load_rgb(n) for n in fixtures.list640()])
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8, keep_levels=False)
+    _compare_all(g, o, imgs, "batch of 5", stages=False)
+
+
+@pytest.mark.parametrize("name", ["blobs.png", "sunflowers.png"])
+def test_parity_odd_sizes(gpu_ctx_factory, name):
+    """500x500 and 768x323: widths that are re-aligned per octave, padded columns scanned."""
+    img = fixtures.load_rgb(name)
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8)
+    _compare_all(g, o, img[None], name)
+
+
+def test_parity_1080p_topk(gpu_ctx_factory):
+    """BASELINE.json configs[1]: 1920x1080 synthetic blobs, default octaves/levels, top-K=4096."""
+    im = fixtures.synthetic_blobs(1920, 1080, 0)
+    kw = dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=4096)
+    g = gpu_ctx_factory(**kw)
+    o = OracleSession(threads=8, **kw)
+    n = _compare_all(g, o, im[None], "1080p top-K 4096")
+    assert len(o.rawlist(0)) == 4096 and n[0] >= 4096
+
+
+@pytest.mark.parametrize("kw", [
+    dict(half_sift=1),
+    dict(max_orientation=1),
+    dict(fixed_orientation=1),
+    dict(subpixel=0),
+    dict(compute_descriptors=0),
+    dict(lowe_origin=1, dog_threshold=0.004, edge_threshold=5.0),
+    dict(dog_level_num=4),
+    dict(first_octave=1),
+    dict(octave_num=2),
+    dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=100),
+    dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=100000),
+    dict(truncate_method=_abi.TRUNC_HIGHEST_0, feature_count_threshold=150),
+    dict(truncate_method=_abi.TRUNC_HIGHEST_1, feature_count_threshold=150),
+    dict(truncate_method=_abi.TRUNC_LOWEST, feature_count_threshold=150),
+    dict(filter_width_factor=5.0, orient_window_factor=1.5, desc_window_factor=2.5),
+])
+def test_parity_parameter_variants(gpu_ctx_factory, kw):
+    img = fixtures.load_rgb("640-2.jpg")
+    g = gpu_ctx_factory(**kw)
+    o = OracleSession(threads=8, keep_levels=False, **kw)
+    _compare_all(g, o, img[None], str(kw), stages=False)
+
+
+@pytest.mark.parametrize("dtype,fmt", [("u8lum", _abi.FMT_LUM), ("u16rgb", _abi.FMT_RGB), ("f32lum", _abi.FMT_LUM),
+                                       ("f32bgr", _abi.FMT_BGR), ("u8rgba", _abi.FMT_RGBA)])
+def test_parity_input_formats(gpu_ctx_factory, dtype, fmt):
+    rgb = fixtures.load_rgb("640-3.jpg")
+    if dtype == "u8lum":
+        img = rgb[..., 1].copy()
+    elif dtype == "u16rgb":
+        img = rgb.astype(np.uint16) * 257
+    elif dtype == "f32lum":
+        img = (rgb[..., 1] / 255.0).astype(np.float32)
+    elif dtype == "f32bgr":
+        img = (rgb[..., ::-1] / 255.0).astype(np.float32)
+    else:
+        img = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8, keep_levels=False)
+    ng = g.run(img[None], fmt=fmt)
+    no = o.run(img[None], fmt=fmt)
+    assert ng == no and no[0] > 50
+    gk, gd = g.fetch(0)
+    ok, od = o.fetch(0)
+    _assert_same_features(gk, gd, ok, od, dtype)
+
+
+def test_edge_cases(gpu_ctx_factory):
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=1)
+    # constant image: no detections, empty outputs
+    flat = np.full((1, 64, 64), 128, np.uint8)
+    assert g.run(flat) == [0] and o.run(flat) == [0]
+    k, d = g.fetch(0)
+    assert len(k) == 0 and d.shape == (0, 128)
+    # smallest supported image and a width that is not a multiple of 4 (columns dropped)
+    rng = np.random.RandomState(3)
+    tiny = (rng.rand(1, 17, 23) * 255).astype(np.uint8)
+    assert g.run(tiny) == o.run(tiny)
+    # image larger than -maxd without -ads: error code, not exit()
+    big = np.zeros((1, 8, 3204), np.uint8)
+    from hessgpu_amd.session import HessError
+    with pytest.raises(HessError) as e:
+        g.run(big)
+    assert e.value.code == _abi.HESS_ERR_TOO_BIG
+    with pytest.raises(HessError):
+        o.run(big)
+    # pyramid reuse after an error and after a size change
+    img = fixtures.load_rgb("640-4.jpg")
+    assert g.run(img[None]) == o.run(img[None])
+
+
+def test_repeatability(gpu_ctx_factory):
+    """speed.cpp:121,149 checks only run-to-run feature count; here the full output must repeat."""
+    img = fixtures.load_rgb("640-5.jpg")
+    g = gpu_ctx_factory()
+    g.run(img[None])
+    k0, d0 = g.fetch(0)
+    for _ in range(3):
+        g.run(img[None])
+        k, d = g.fetch(0)
+        assert k.tobytes() == k0.tobytes() and d.tobytes() == d0.tobytes()
