@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Hessian + SIFT hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1: run directly)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W        (N>1, one rank per GPU)
+
+Metric (BASELINE.json): Mpixels/s end-to-end (pyramid -> descriptor) on 1920x1080 images.
+Workload = BASELINE.json configs[1]: 1920x1080 synthetic blobs, default octaves / DoG levels,
+top-K = 4096.  A step = one pass of the hot path over one batch of `--batch` images per GPU, the
+u8 luminance pixels already resident in HBM when the timed region starts; a step ends with the
+keypoints + descriptors of the batch in host memory (hess_run_device returns) and, for N > 1,
+the RCCL gather of the feature lists to rank 0.  Weak scaling: per-GPU work is fixed.
+
+Adds to the contract's JSON line:
+  roofline      dominant kernel (separable Gaussian): algorithmic bytes per launch / average launch
+                duration measured with hipEvents on the context's stream during the timed region
+  cpu_baseline  the CPU oracle (a port of the reference's CUDA path; the reference has no CPU
+                path) timed on rank 0's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, TOPK = 1920, 1080, 4096
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images per GPU (tiled to --batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import fixtures  # tests/fixtures.py: the synthetic generator of configs[1]
+    import hessgpu_amd
+    from hessgpu_amd import _abi, dist as hdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as tdist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group(backend="nccl", device_id=dev)
+
+    B = args.batch
+    nd = max(1, min(args.distinct, B))
+    imgs = np.stack([fixtures.synthetic_blobs(W, H, rank * B + i) for i in range(nd)])
+    imgs = np.concatenate([imgs] * ((B + nd - 1) // nd))[:B]
+    d_imgs = torch.from_numpy(imgs).to(dev)  # [B,H,W] u8 resident in HBM
+
+    ctx = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK)
+    ctx.reserve(W, H, B)
+
+    def step():
+        ctx.run_device(d_imgs.data_ptr(), B, H, W)
+        counts = [ctx.count(b) for b in range(B)]
+        if use_dist:
+            keys, desc = hdist.device_feature_tensors(ctx, counts, dev)
+            hdist.gather_feature_lists(counts, keys, desc, dst=0)
+        return counts
+
+    def fence():
+        if use_dist:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts = step()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ctx.profile() if not args.no_profile else None
+    ctx.profile_enable(False)
+
+    if rank == 0:
+        pixels = float(world) * B * args.steps * W * H
+        value = pixels / dt / 1e6
+        out = {
+            "metric": "Mpixels/s end-to-end (pyramid->descriptor), 1920x1080",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "1920x1080 synthetic blobs (tests/fixtures.py), default octaves/DoG levels, top-K=4096",
+                "images_per_gpu_per_step": B,
+                "distinct_images_per_gpu": nd,
+                "features_per_image_mean": round(float(np.mean(counts)), 1),
+                "sharding": f"images over {world} rank(s), RCCL gather of feature lists" if use_dist else "single GPU",
+                "input": "u8 luminance resident in HBM; results delivered to host memory",
+            },
+        }
+        if prof is not None:
+            g = prof["gauss"]
+            if g["launches"]:
+                achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+                out["roofline"] = {
+                    "bound": "hbm",
+                    "kernel": "gauss_kernel (separable Gaussian, one pyramid level of the batch per launch)",
+                    "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": _traffic_from_profiles(),
+                    "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
+                    "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"], 1),
+                    "launches": g["launches"],
+                }
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(imgs[:nd])
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if use_dist:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+def _traffic_from_profiles():
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass, if one exists."""
+    p = os.path.join(ROOT, "profiles", "gauss_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _host_cores():
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask; capped at 16
+    (the GPU box gives one GPU's job 16 cores; more OpenMP threads than that only oversubscribe)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(sample_imgs):
+    """The CPU oracle on the same workload, all host cores (OpenMP), bounded sample."""
+    import numpy as np
+    from hessgpu_amd import _abi
+    from oracle_lib import OracleSession  # the checker, timed here as the CPU baseline only
+
+    cores = _host_cores()
+    o = OracleSession(threads=cores, keep_levels=False, truncate_method=_abi.TRUNC_TOPK,
+                      feature_count_threshold=TOPK)
+    o.run(sample_imgs[:1])  # warm-up (page faults, OpenMP pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for i in range(len(sample_imgs)):
+            o.run(sample_imgs[i:i + 1])
+            n += 1
+        if time.perf_counter() - t0 > 10.0 or n >= 256:
+            break
+    dt = time.perf_counter() - t0
+    o.close()
+    return {
+        "value": round(n * W * H / dt / 1e6, 2),
+        "unit": "Mpix/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} runs of the bench workload (1920x1080, top-K 4096) in {dt:.1f} s, "
+                  f"oracle/hess_oracle.c with {cores} OpenMP threads",
+    }
+
+
+if __name__ == "__main__":
+    main()

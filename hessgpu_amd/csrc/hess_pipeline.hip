@@ -671,6 +671,14 @@ int hess_fetch(hess_ctx* c, int img, hess_keypoint* keys, float* desc) {
   return 0;
 }
 
+int hess_device_results(hess_ctx* c, const void** keys, const void** desc, int* capacity) {
+  if (!c || !c->batch) return HESS_ERR_STATE;
+  if (keys) *keys = c->keys.p;
+  if (desc) *desc = c->dim ? c->desc.p : nullptr;
+  if (capacity) *capacity = c->cap_feat;
+  return 0;
+}
+
 int hess_geometry(hess_ctx* c, int* widths, int* heights) {
   if (!c || !c->planned) return HESS_ERR_STATE;
   for (int o = 0; o < c->g.noct; o++) {

@@ -1,0 +1,98 @@
+"""Image-level sharding over ranks and the gather of the final feature lists.
+
+The path shards trivially: every image is independent (the reference runs one SiftGPU instance
+per device, TestWin/MultiThreadSIFT.cpp:231-244, or one TCP server process per GPU,
+ServerSiftGPU.cpp:156-194).  Here: one process per GPU, image i of a batch goes to the rank that
+owns the contiguous block containing i, each rank runs the whole path locally, and the only
+exchange step is the gather of the variable-length feature lists to one rank -- an all_gather of
+the per-image counts followed by one padded gather of keypoints and one of descriptors
+(torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+KEY_BYTES = 24  # sizeof(hess_keypoint) = sizeof(SiftGPU::SiftKeypoint)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition of range(n_items): -> (first, last_exclusive) of `rank`."""
+    base, rem = divmod(n_items, world)
+    first = rank * base + min(rank, rem)
+    return first, first + base + (1 if rank < rem else 0)
+
+
+def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
+    """Gather per-image feature lists to rank `dst`.
+
+    counts    list[int], features per local image (same number of local images on every rank)
+    keys_u8   uint8 tensor [sum(counts), 24]  (hess_keypoint records, local images back to back)
+    desc_f32  float32 tensor [sum(counts), dim] or None when descriptors are off
+    Returns on dst: (all_counts [world][n_local], keys list[world] of uint8 [n_r,24],
+    desc list[world] of float32 [n_r,dim] or None); on other ranks (all_counts, None, None).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = keys_u8.device
+    local = torch.tensor(counts, dtype=torch.int32, device=dev)
+    allc = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(allc, local, group=group)
+    all_counts = [c.tolist() for c in allc]
+    totals = [int(sum(c)) for c in all_counts]
+    pad = max(max(totals), 1)
+
+    def padded(t, width, dtype):
+        out = torch.zeros((pad, width), dtype=dtype, device=dev)
+        if t is not None and t.shape[0]:
+            out[: t.shape[0]] = t
+        return out
+
+    kp = padded(keys_u8, KEY_BYTES, torch.uint8)
+    klist = [torch.empty_like(kp) for _ in range(world)] if rank == dst else None
+    dist.gather(kp, gather_list=klist, dst=dst, group=group)
+    dlist = None
+    if desc_f32 is not None:
+        dp = padded(desc_f32, desc_f32.shape[1], torch.float32)
+        dlist = [torch.empty_like(dp) for _ in range(world)] if rank == dst else None
+        dist.gather(dp, gather_list=dlist, dst=dst, group=group)
+    if rank != dst:
+        return all_counts, None, None
+    keys = [klist[r][: totals[r]] for r in range(world)]
+    desc = [dlist[r][: totals[r]] for r in range(world)] if dlist is not None else None
+    return all_counts, keys, desc
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_feature_tensors(ctx, counts, device):
+    """Pack the device-resident results of the last run (hess_device_results) of every local image
+    back to back: -> (keys uint8 [total,24], desc float32 [total,dim] or None), on `device`."""
+    kptr, dptr, cap = ctx.device_results()
+    dim = ctx.desc_dim()
+    nb = len(counts)
+    kall = torch.as_tensor(_DevArray(kptr, (nb, cap, KEY_BYTES), "|u1"), device=device)
+    keys = torch.cat([kall[b, : counts[b]] for b in range(nb)]) if nb else kall.reshape(0, KEY_BYTES)
+    desc = None
+    if dim and dptr:
+        dall = torch.as_tensor(_DevArray(dptr, (nb, cap, dim), "<f4"), device=device)
+        desc = torch.cat([dall[b, : counts[b]] for b in range(nb)])
+    return keys, desc
+
+
+def host_feature_tensors(session, counts):
+    """Same packing from host results (any backend): used by the gloo CPU tests."""
+    ks, ds = [], []
+    for b in range(len(counts)):
+        k, d = session.fetch(b)
+        ks.append(np.frombuffer(k.tobytes(), dtype=np.uint8).reshape(-1, KEY_BYTES))
+        ds.append(d)
+    keys = torch.from_numpy(np.concatenate(ks).copy()) if ks else torch.zeros((0, KEY_BYTES), dtype=torch.uint8)
+    dim = session.desc_dim()
+    desc = torch.from_numpy(np.concatenate(ds).copy()) if dim else None
+    return keys, desc

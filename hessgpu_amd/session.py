@@ -140,6 +140,12 @@ class Session:
         p = self._f["timing"](self._h)
         return np.array([p[i] for i in range(_abi.T_COUNT)], dtype=np.float32)
 
+    def device_results(self):
+        """-> (keys_ptr, desc_ptr, capacity): device buffers of the last run (product only)."""
+        k, d, cap = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._check(self._f["device_results"](self._h, C.byref(k), C.byref(d), C.byref(cap)))
+        return k.value, d.value, cap.value
+
     # -- profiling (product only) --------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._f["profile_enable"](self._h, int(on)))

@@ -145,6 +145,11 @@ int hess_desc_dim(hess_ctx* ctx);
  * Either output may be NULL.  keys: hess_count() records; desc: hess_count()*hess_desc_dim() floats. */
 int hess_fetch(hess_ctx* ctx, int img, hess_keypoint* keys, float* desc);
 
+/* Device-resident results of the last run, for consumers that stay on the GPU (the multi-GPU
+ * gather over RCCL): keys = [batch][capacity] hess_keypoint, desc = [batch][capacity][dim] float,
+ * image b holds hess_count(b) valid records.  Pointers stay valid until the next run. */
+int hess_device_results(hess_ctx* ctx, const void** keys, const void** desc, int* capacity);
+
 /* Pyramid geometry of the last run (PyramidCU.cpp:238-245,274-309): number of octaves, and per
  * octave the aligned width / height. Arrays must hold >= 32 entries. Returns octave count. */
 int hess_geometry(hess_ctx* ctx, int* widths, int* heights);
