@@ -137,14 +137,14 @@ void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, c
 // (ReshapeFeatureListCPU, PyramidCU.cpp:720-924; LimitFeatureCount(1)).
 void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi,
                          const RawKey* list, const int* list_total, int cap_list, const int* ocount,
-                         int* foffset, int* feat_total, int* feat_first, int cap_feat, int* overflow,
-                         int batch);
+                         int* foffset, int* fsrc, int* feat_total, int* feat_first, int cap_feat,
+                         int* overflow, int batch);
 // Descriptor + normalisation + host keypoint record (ComputeDescriptor_Kernel /
 // NormalizeDescriptor_Kernel, ProgramCU.cu:1650-2054; keypoint unpack PyramidCU.cpp:866-906).
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
-                       const int* list_total, int cap_list, const FRec* recs, const int* ocount,
-                       const int* foffset, const int* feat_total, const int* feat_first,
-                       const float* got, HostKeypoint* keys, float* desc, int cap_feat, int batch);
+                       int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
+                       const int* feat_first, const float* got, HostKeypoint* keys, float* desc,
+                       int cap_feat, int batch);
 
 // Device evaluation of the elementary functions for the parity tests.
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);

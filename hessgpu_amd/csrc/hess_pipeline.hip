@@ -66,7 +66,7 @@ struct hess_ctx {
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
   DevBuf gauss, deth, got, input_f32, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
-      hist, sel_total, sel_level_count, recs, ocount, foffset, feat_total, feat_first, keys, desc;
+      hist, sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, keys, desc;
   // host results
   int batch = 0;
   std::vector<int> counts;
@@ -307,6 +307,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->recs, (size_t)B * cap_sel * sizeof(FRec)))) return rc;
   if ((rc = ensure(c, c->ocount, (size_t)B * cap_sel * 4))) return rc;
   if ((rc = ensure(c, c->foffset, (size_t)B * cap_sel * 4))) return rc;
+  if ((rc = ensure(c, c->fsrc, (size_t)B * cap_feat * 4))) return rc;
   if ((rc = ensure(c, c->keys, (size_t)B * cap_feat * sizeof(HostKeypoint)))) return rc;
   if (c->dim && (rc = ensure(c, c->desc, (size_t)B * cap_feat * c->dim * 4))) return rc;
   if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 4) * 4, true))) return rc;
@@ -475,7 +476,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   (void)hipEventRecord(c->ev[5], st);
   // ---- multi-orientation expansion (ReshapeFeatureListCPU) ----
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
-                      (int*)c->foffset.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
+                      (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p + 1, batch);
   (void)hipEventRecord(c->ev[6], st);
   // ---- descriptors (GetFeatureDescriptors) ----
@@ -489,8 +490,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.dog = g.dog;
   {
     ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
-    launch_descriptor(st, g, dsp, list, list_total, cap_list, (const FRec*)c->recs.p, (const int*)c->ocount.p,
-                      (const int*)c->foffset.p, (const int*)c->feat_total.p, (const int*)c->feat_first.p, got,
+    launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
+                      (const int*)c->feat_total.p, (const int*)c->feat_first.p, got,
                       (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, batch);
   }
   (void)hipEventRecord(c->ev[7], st);
@@ -602,7 +603,7 @@ void hess_destroy(hess_ctx* c) {
   if (c->st) (void)hipStreamSynchronize(c->st);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->overflow, &c->raw, &c->sel, &c->hist, &c->sel_total,
-                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->feat_total, &c->feat_first,
+                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first,
                     &c->keys, &c->desc};
   for (DevBuf* b : bufs) release(*b);
   release(c->h_keys, true);

@@ -220,8 +220,8 @@ __device__ __forceinline__ int block_scan1(int a, int* total, int* lds) {
 
 __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams lp, int multi, const RawKey* list,
                                                             const int* list_total, int cap_list, const int* ocount,
-                                                            int* foffset, int* feat_total, int* feat_first,
-                                                            int cap_feat, int* overflow) {
+                                                            int* foffset, int* fsrc, int* feat_total,
+                                                            int* feat_first, int cap_feat, int* overflow) {
   __shared__ int lds[64];
   __shared__ int lc[kMaxOct * kMaxDog];
   __shared__ int carry;
@@ -240,7 +240,13 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
     int tot;
     const int e = block_scan1(c, &tot, lds);
     const int cb = carry;
-    if (i < n) foffset[(long long)b * cap_list + i] = cb + e;
+    if (i < n) {
+      foffset[(long long)b * cap_list + i] = cb + e;
+      // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
+      // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
+      for (int k = 0; k < c; k++)
+        if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = i * 4 + k;
+    }
     __syncthreads();
     if (tid == 0) carry = cb + tot;
     __syncthreads();
@@ -267,28 +273,22 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 // ================================= descriptor ================================================
 
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
-                                                         const int* list_total, int cap_list, const FRec* recs,
-                                                         const int* ocount, const int* foffset,
-                                                         const int* feat_total, const int* feat_first,
-                                                         const float* got, HostKeypoint* keys, float* desc,
-                                                         int cap_feat) {
+                                                         int cap_list, const FRec* recs,
+                                                         const int* fsrc, const int* feat_total,
+                                                         const int* feat_first, const float* got,
+                                                         HostKeypoint* keys, float* desc, int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
+  __shared__ float2 rec_lds[4][16][64];  // per wavefront: one round's (theta, weight) records per cell
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  const int n = list_total[b];
   const int ftotal = feat_total[b], ffirst = feat_first[b];
   const int nwaves = gridDim.x * 4;
-  const int per_kp = dp.multi ? 4 : 1;
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;
 
-  for (int wid = blockIdx.x * 4 + wv; wid < n * per_kp; wid += nwaves) {
-    const int i = dp.multi ? (wid >> 2) : wid;
-    const int k = dp.multi ? (wid & 3) : 0;
-    const int cnt = dp.multi ? ocount[(long long)b * cap_list + i] : 1;
-    if (k >= cnt) continue;
-    const int m = foffset[(long long)b * cap_list + i] + k;
-    if (m < ffirst || m >= ffirst + ftotal) continue;
+  for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
+    const int src = fsrc[(long long)b * cap_feat + m];
+    const int i = src >> 2, k = src & 3;
     const int oidx = m - ffirst;
     const FRec rec = recs[(long long)b * cap_list + i];
     const int li = list[(long long)b * cap_list + i].level_index;
@@ -328,26 +328,47 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     const float crspt = c / spt, srspt = s / spt;
     const float bsz = fabsf(cspt) + fabsf(sspt);
 
-    for (int cell = 0; cell < 16; cell++) {
-      const int ix = cell & 3, iy = cell >> 2;
-      const float offx = ix - 1.5f, offy = iy - 1.5f;
-      const float ptx = fmaf(cspt, offx, -(sspt * offy)) + kx;
-      const float pty = fmaf(cspt, offy, sspt * offx) + ky;
-      const float xmin = fmaxf(1.5f, floorf(ptx - bsz) + 0.5f);
-      const float ymin = fmaxf(1.5f, floorf(pty - bsz) + 0.5f);
-      const float xmax = fminf(width - 1.5f, floorf(ptx + bsz) + 0.5f);
-      const float ymax = fminf(height - 1.5f, floorf(pty + bsz) + 0.5f);
-      const int nxs = (xmax >= xmin) ? (int)(xmax - xmin) + 1 : 0;
-      const int nys = (ymax >= ymin) ? (int)(ymax - ymin) + 1 : 0;
-      const int total = nxs * nys;
-      float des = 0.0f;  // lane j < 9 owns des[j]
-      for (int t0 = 0; t0 < total; t0 += 64) {
+    // Cell geometry (ProgramCU.cu:1692-1716): lane c < 16 holds the constants of cell c.
+    const int cc_ = lane & 15;
+    const float offx_l = (cc_ & 3) - 1.5f, offy_l = (cc_ >> 2) - 1.5f;
+    const float ptx_l = fmaf(cspt, offx_l, -(sspt * offy_l)) + kx;
+    const float pty_l = fmaf(cspt, offy_l, sspt * offx_l) + ky;
+    const float xmin_l = fmaxf(1.5f, floorf(ptx_l - bsz) + 0.5f);
+    const float ymin_l = fmaxf(1.5f, floorf(pty_l - bsz) + 0.5f);
+    const float xmax_l = fminf(width - 1.5f, floorf(ptx_l + bsz) + 0.5f);
+    const float ymax_l = fminf(height - 1.5f, floorf(pty_l + bsz) + 0.5f);
+    const int nxs_l = (xmax_l >= xmin_l) ? (int)(xmax_l - xmin_l) + 1 : 0;
+    const int nys_l = (ymax_l >= ymin_l) ? (int)(ymax_l - ymin_l) + 1 : 0;
+    const int total_l = nxs_l * nys_l;
+    const float inv_l = 1.0f / (float)(nxs_l > 0 ? nxs_l : 1);
+    int maxtotal = total_l;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) maxtotal = max(maxtotal, __shfl_xor(maxtotal, d));
+    maxtotal = rli(maxtotal, 0);
+
+    // Accumulators: lane = cell*4 + sub owns des[sub], des[sub+4] of its cell; sub 0 also des[8].
+    const int mycell = lane >> 2, sub = lane & 3;
+    float acc_lo = 0.0f, acc_hi = 0.0f, acc_8 = 0.0f;
+    float2* rlist = &rec_lds[wv][0][0];
+
+    for (int t0 = 0; t0 < maxtotal; t0 += 64) {
+      // ---- phase 1: 64 samples of every cell's box, hits appended in scan order to the cell's list ----
+      int cnt_l = 0;  // lane c < 16: records of cell c in this round
+      int cntmax = 0;
+      for (int cell = 0; cell < 16; cell++) {
+        const int tot_c = rli(total_l, cell);
+        if (t0 >= tot_c) continue;
+        const float ptx = rl(ptx_l, cell), pty = rl(pty_l, cell);
+        const float xmin = rl(xmin_l, cell), ymin = rl(ymin_l, cell);
+        const float offx = rl(offx_l, cell), offy = rl(offy_l, cell);
+        const float inv = rl(inv_l, cell);
+        const int nxs = rli(nxs_l, cell);
         const int t = t0 + lane;
         bool hit = false;
-        int fidx = 0;
-        float w1 = 0, w2 = 0, wt = 0;
-        if (t < total) {
-          const int sy = t / nxs, sx = t - sy * nxs;
+        float theta = 0.0f, wt = 0.0f;
+        if (t < tot_c) {
+          const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
+          const int sx = t - sy * nxs;
           const float x = xmin + (float)sx, y = ymin + (float)sy;
           const float dx = x - ptx, dy = y - pty;
           const float nx = fmaf(crspt, dx, srspt * dy);
@@ -359,33 +380,53 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
             const float ww = dm_expf(-0.125f * fmaf(dnx, dnx, dny * dny));
             const float wx = 1.0f - nxn, wy = 1.0f - nyn;
             wt = ww * wx * wy * cc.x;
-            float theta = (anglef - cc.y) * rpi;
+            theta = (anglef - cc.y) * rpi;
             if (theta < 0) theta += 8.0f;
-            const float fo = floorf(theta);
-            fidx = (int)fo;
-            w1 = fo + 1.0f - theta;
-            w2 = theta - fo;
-            hit = (fidx >= 0) && (fidx < 8);  // DYNAMIC_INDEXING=false: only k==fidx, k<8 (ProgramCU.cu:1763-1771)
+            // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771)
+            hit = (theta >= 0.0f) && (theta < 8.0f);
           }
         }
-        uint64_t mk = __ballot(hit);
-        while (mk) {
-          const int j = __builtin_ctzll(mk);
-          mk &= mk - 1;
-          const int fj = rli(fidx, j);
-          const float w1j = rl(w1, j), w2j = rl(w2, j), wj = rl(wt, j);
-          if (lane == fj) des = fmaf(w1j, wj, des);
-          if (lane == fj + 1) des = fmaf(w2j, wj, des);
+        const uint64_t mk = __ballot(hit);
+        if (hit) rlist[cell * 64 + __popcll(mk & ((1ull << lane) - 1ull))] = make_float2(theta, wt);
+        const int nrec = __popcll(mk);
+        if (lane == cell) cnt_l = nrec;
+        cntmax = max(cntmax, nrec);
+      }
+      // ---- phase 2: the four lanes of a cell walk its list in order; one fmaf per record and lane ----
+      const int nmine = __shfl(cnt_l, mycell);
+      const float2* mylist = rlist + mycell * 64;
+      for (int step0 = 0; step0 < cntmax; step0 += 4) {
+        float2 r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) r4[u] = mylist[min(step0 + u, 63)];  // issue the LDS reads together
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (step0 + u < nmine) {
+            const float2 r = r4[u];
+            const float fo = floorf(r.x);
+            const int fidx = (int)fo;
+            const float w1 = fo + 1.0f - r.x;   // ProgramCU.cu:1752
+            const float w2 = r.x - fo;          // ProgramCU.cu:1753
+            const bool is1 = ((fidx & 3) == sub);          // des[fidx]   += w1*weight
+            const bool is2 = (((fidx + 1) & 3) == sub);    // des[fidx+1] += w2*weight
+            const int tgt = is1 ? fidx : fidx + 1;
+            const float coef = is1 ? w1 : w2;
+            const float base = (tgt < 4) ? acc_lo : ((tgt < 8) ? acc_hi : acc_8);
+            const float upd = fmaf(coef, r.y, base);
+            const bool act = is1 || is2;
+            if (act && tgt < 4) acc_lo = upd;
+            else if (act && tgt < 8) acc_hi = upd;
+            else if (act) acc_8 = upd;
+          }
         }
       }
-      const float d8 = rl(des, 8);
-      if (lane == 0) des += d8;  // des[0] += des[8], ProgramCU.cu:1776
-      if (dp.half_sift) {
-        const float hi = __shfl(des, (lane + 4) & 63);
-        if (lane < 4) { des += hi; dl[wv][cell * 4 + lane] = des; }
-      } else {
-        if (lane < 8) dl[wv][cell * 8 + lane] = des;
-      }
+    }
+    if (sub == 0) acc_lo += acc_8;  // des[0] += des[8], ProgramCU.cu:1776
+    if (dp.half_sift) {
+      dl[wv][mycell * 4 + sub] = acc_lo + acc_hi;  // des[k] += des[k+4], ProgramCU.cu:1782-1785
+    } else {
+      dl[wv][mycell * 8 + sub] = acc_lo;
+      dl[wv][mycell * 8 + 4 + sub] = acc_hi;
     }
     // same wavefront wrote dl[wv]; LDS operations of one wavefront complete in order
     float* dout = desc + ((long long)b * cap_feat + oidx) * dim;
@@ -438,22 +479,21 @@ void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, c
 }
 
 void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi, const RawKey* list,
-                         const int* list_total, int cap_list, const int* ocount, int* foffset, int* feat_total,
-                         int* feat_first, int cap_feat, int* overflow, int batch) {
+                         const int* list_total, int cap_list, const int* ocount, int* foffset, int* fsrc,
+                         int* feat_total, int* feat_first, int cap_feat, int* overflow, int batch) {
   hipLaunchKernelGGL(feature_scan_kernel, dim3(batch), dim3(1024), 0, st, g, lp, multi, list, list_total, cap_list,
-                     ocount, foffset, feat_total, feat_first, cap_feat, overflow);
+                     ocount, foffset, fsrc, feat_total, feat_first, cap_feat, overflow);
 }
 
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
-                       const int* list_total, int cap_list, const FRec* recs, const int* ocount,
-                       const int* foffset, const int* feat_total, const int* feat_first, const float* got,
-                       HostKeypoint* keys, float* desc, int cap_feat, int batch) {
-  long long waves = (long long)cap_list * (dp.multi ? 4 : 1);
-  int blocks = (int)((waves + 3) / 4);
-  if (blocks > 4096) blocks = 4096;
+                       int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
+                       const int* feat_first, const float* got, HostKeypoint* keys, float* desc, int cap_feat,
+                       int batch) {
+  int blocks = (cap_feat + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), 0, st, g, dp, list, list_total, cap_list,
-                     recs, ocount, foffset, feat_total, feat_first, got, keys, desc, cap_feat);
+  hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), 0, st, g, dp, list, cap_list, recs, fsrc,
+                     feat_total, feat_first, got, keys, desc, cap_feat);
 }
 
 }  // namespace hess
