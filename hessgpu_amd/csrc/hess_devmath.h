@@ -38,20 +38,20 @@ __device__ __forceinline__ float dm_expf(float x) {
 // a^e from ln(a): the orientation kernel's pow(sigma_step, ds) (ProgramCU.cu:1297).
 __device__ __forceinline__ float dm_powf_ln(float ln_a, float e) { return dm_expf(e * ln_a); }
 
+// atan on [0,1]: t + t^3*q(t^2), q of degree 8 (relative-error-weighted least-squares fit).
 __device__ __forceinline__ float dm_atan01(float t) {
-  float y0 = 0.0f;
-  if (t > 0.4142135623730950f) {
-    y0 = 0.785398163397448309f;
-    t = (t - 1.0f) / (t + 1.0f);
-  }
   float z = t * t;
-  float p = 8.05374449538e-2f;
-  p = fmaf(p, z, -1.38776856032E-1f);
-  p = fmaf(p, z, 1.99777106478E-1f);
-  p = fmaf(p, z, -3.33329491539E-1f);
-  p = p * z;
-  p = fmaf(p, t, t);
-  return y0 + p;
+  float q = -0.0017890612361952662f;
+  q = fmaf(q, z, 0.010897884145379066f);
+  q = fmaf(q, z, -0.03115503303706646f);
+  q = fmaf(q, z, 0.057945046573877335f);
+  q = fmaf(q, z, -0.08403480052947998f);
+  q = fmaf(q, z, 0.10952533036470413f);
+  q = fmaf(q, z, -0.14264392852783203f);
+  q = fmaf(q, z, 0.19998574256896973f);
+  q = fmaf(q, z, -0.33333301544189453f);
+  q = q * z;
+  return fmaf(q, t, t);
 }
 
 // atan2(y,x) in [-pi, pi]; (0,0) -> 0.

@@ -4,7 +4,7 @@
  * not present here.  Each is a fixed sequence of IEEE-754 binary32
  * operations (+, *, fmaf, /, rintf) so that a second implementation of the same sequence --
  * the HIP kernels' own copy in hessgpu_amd/csrc/hess_devmath.h -- gives bit-identical
- * results.  Algorithms: Cephes single-precision expf / atanf / sinf / cosf (S. Moshier,
+ * results.  Algorithms: Cephes single-precision expf / sinf / cosf (S. Moshier; atan: own fit,
  * public algorithm and coefficients), restated.  Accuracy is checked against libm in
  * tests/test_oracle_math.py (<= 2 ulp on the ranges the hot path uses), i.e. inside the
  * error bound CUDA documents for expf/atan2f/sinf/cosf.
@@ -47,21 +47,21 @@ static inline float om_expf(float x) {
 /* a^e given ln(a) rounded to float: the reference's pow(sigma_step, ds). */
 static inline float om_powf_ln(float ln_a, float e) { return om_expf(e * ln_a); }
 
-/* atan on [0,1] (argument already reduced to min/max). */
+/* atan on [0,1] (argument already reduced to min/max): t + t^3*q(t^2), q = degree-8 least-squares
+ * fit on Chebyshev nodes (relative-error weighted); measured <= 1.6 ulp, no range reduction. */
 static inline float om_atan01(float t) {
-  float y0 = 0.0f;
-  if (t > 0.4142135623730950f) { /* tan(pi/8) */
-    y0 = 0.785398163397448309f;
-    t = (t - 1.0f) / (t + 1.0f);
-  }
   float z = t * t;
-  float p = 8.05374449538e-2f;
-  p = fmaf(p, z, -1.38776856032E-1f);
-  p = fmaf(p, z, 1.99777106478E-1f);
-  p = fmaf(p, z, -3.33329491539E-1f);
-  p = p * z;
-  p = fmaf(p, t, t);
-  return y0 + p;
+  float q = -0.0017890612361952662f;
+  q = fmaf(q, z, 0.010897884145379066f);
+  q = fmaf(q, z, -0.03115503303706646f);
+  q = fmaf(q, z, 0.057945046573877335f);
+  q = fmaf(q, z, -0.08403480052947998f);
+  q = fmaf(q, z, 0.10952533036470413f);
+  q = fmaf(q, z, -0.14264392852783203f);
+  q = fmaf(q, z, 0.19998574256896973f);
+  q = fmaf(q, z, -0.33333301544189453f);
+  q = q * z;
+  return fmaf(q, t, t);
 }
 
 /* atan2(y, x), result in [-pi, pi]; (0,0) -> 0. */

@@ -1,0 +1,109 @@
+"""Multi-rank path on CPU: world_size 2 over gloo.  Images are sharded by contiguous blocks, each
+rank runs the path on its shard (here with the CPU oracle standing in for the per-rank backend,
+since there is no GPU), and the feature lists are gathered to rank 0 exactly as bench.py does
+over RCCL.  Rank 0 checks the gathered lists against a single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fixtures
+from hessgpu_amd import dist as hdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 5, 8, 63, 64):
+        for world in (1, 2, 3, 8):
+            spans = [hdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, result_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import OracleSession
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        first, last = hdist.shard_range(n_images, rank, world)
+        imgs = np.stack([fixtures.synthetic_blobs(160, 120, i) for i in range(first, last)])
+        o = OracleSession(threads=1, keep_levels=False, truncate_method=3, feature_count_threshold=64)
+        counts = o.run(imgs)
+        keys, desc = hdist.host_feature_tensors(o, counts)
+        all_counts, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0)
+        if rank == 0:
+            flat_counts = [c for r in all_counts for c in r]
+            np.savez(result_path, counts=np.array(flat_counts),
+                     keys=np.concatenate([k.numpy() for k in gk]), desc=np.concatenate([d.numpy() for d in gd]))
+        else:
+            assert gk is None and gd is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_matches_single_process(tmp_path):
+    from oracle_lib import OracleSession
+
+    n_images, world = 4, 2
+    out = str(tmp_path / "gathered.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n_images, out), nprocs=world, join=True)
+    got = np.load(out)
+    imgs = np.stack([fixtures.synthetic_blobs(160, 120, i) for i in range(n_images)])
+    o = OracleSession(threads=1, keep_levels=False, truncate_method=3, feature_count_threshold=64)
+    counts = o.run(imgs)
+    assert got["counts"].tolist() == counts and sum(counts) > 0
+    ks, ds = [], []
+    for b in range(n_images):
+        k, d = o.fetch(b)
+        ks.append(np.frombuffer(k.tobytes(), np.uint8).reshape(-1, 24))
+        ds.append(d)
+    assert np.array_equal(got["keys"], np.concatenate(ks))
+    assert np.array_equal(got["desc"].view(np.uint32), np.concatenate(ds).view(np.uint32))
+
+
+def test_gather_handles_ranks_with_no_features(tmp_path):
+    """Empty and ragged lists: one rank contributes nothing (SURVEY 8c edge cases)."""
+    out = str(tmp_path / "g2.npz")
+    mp.spawn(_ragged_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got["counts"].tolist() == [0, 3]
+    assert got["keys"].shape == (3, 24) and got["desc"].shape == (3, 128)
+    assert np.array_equal(got["desc"][:, 0], np.array([1.0, 2.0, 3.0], np.float32))
+
+
+def _ragged_worker(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 0 if rank == 0 else 3
+        keys = torch.full((n, 24), rank, dtype=torch.uint8)
+        desc = torch.arange(1, n + 1, dtype=torch.float32)[:, None].repeat(1, 128)
+        all_counts, gk, gd = hdist.gather_feature_lists([n], keys, desc, dst=0)
+        if rank == 0:
+            np.savez(result_path, counts=np.array([c for r in all_counts for c in r]),
+                     keys=np.concatenate([k.numpy() for k in gk]), desc=np.concatenate([d.numpy() for d in gd]))
+    finally:
+        dist.destroy_process_group()
