@@ -1,0 +1,641 @@
+// siftgpu_api.cpp -- the SiftGPU C++ plugin surface (include/SiftGPU.h) implemented on the C ABI
+// of include/hess_abi.h.  Host C++ only: no OpenGL, CUDA or DevIL.  Behaviour follows the
+// reference's SiftGPU.cpp (argv-style ParseParam with its first-four-characters option matching,
+// RunSIFT overloads, GetFeatureVector, SaveSIFT formats, _timing[] indices) and
+// GLTexImage.cpp's built-in PNM loader; citations per function.
+#include "../../include/SiftGPU.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hess_abi.h"
+
+namespace {
+
+// OpenGL enumerants accepted by RunSIFT(w,h,data,format,type) (GLTexImage.cpp IsSimpleGlFormat).
+enum : unsigned {
+  kGL_LUMINANCE = 0x1909, kGL_LUMINANCE_ALPHA = 0x190A, kGL_RGB = 0x1907, kGL_RGBA = 0x1908,
+  kGL_BGR = 0x80E0, kGL_BGRA = 0x80E1, kGL_UNSIGNED_BYTE = 0x1401, kGL_UNSIGNED_SHORT = 0x1403,
+  kGL_FLOAT = 0x1406
+};
+
+// Everything the reference keeps in process-global statics (GlobalUtil.h:35-111) lives per instance.
+struct Impl {
+  hess_params p;
+  hess_ctx* ctx = nullptr;
+  bool dirty = true;          // parameters changed since the context was created
+  int device = 0;
+  int verbose = 1, timingS = 1, timingO = 0, timingL = 0;  // GlobalUtil.cpp:51-54
+  int binary_sift = 0;        // 0 text, 1 binary, 2 vlfeat (-b, -bvlf)
+  int init_w = 0, init_h = 0; // -p WxH
+  int tight = 0;
+  float mr_size = 3.0f;       // GlobalUtil.cpp:93
+  std::vector<std::string> list;
+  // current image (a copy: the reference borrows the caller's pointer only during the call)
+  std::vector<unsigned char> pixels;
+  int w = 0, h = 0, fmt = 0, pix = 0;
+  // results of the last run
+  std::vector<hess_keypoint> keys;
+  std::vector<float> desc;
+  int nfeat = 0, dim = 0;
+  bool warned_keylist = false;
+};
+
+inline Impl* I(SiftPyramid* p) { return reinterpret_cast<Impl*>(p); }
+
+int gl_to_hess(unsigned gl_format, unsigned gl_type, int* fmt, int* pix) {
+  switch (gl_format) {
+    case kGL_LUMINANCE: *fmt = HESS_FMT_LUM; break;
+    case kGL_LUMINANCE_ALPHA: *fmt = HESS_FMT_LUM_ALPHA; break;
+    case kGL_RGB: *fmt = HESS_FMT_RGB; break;
+    case kGL_RGBA: *fmt = HESS_FMT_RGBA; break;
+    case kGL_BGR: *fmt = HESS_FMT_BGR; break;
+    case kGL_BGRA: *fmt = HESS_FMT_BGRA; break;
+    default: return 0;
+  }
+  switch (gl_type) {
+    case kGL_UNSIGNED_BYTE: *pix = HESS_PIX_U8; break;
+    case kGL_UNSIGNED_SHORT: *pix = HESS_PIX_U16; break;
+    case kGL_FLOAT: *pix = HESS_PIX_F32; break;
+    default: return 0;
+  }
+  return 1;
+}
+
+int channels(int fmt) { return fmt == HESS_FMT_LUM ? 1 : fmt == HESS_FMT_LUM_ALPHA ? 2 : (fmt == HESS_FMT_RGB || fmt == HESS_FMT_BGR) ? 3 : 4; }
+int pix_bytes(int pix) { return pix == HESS_PIX_U8 ? 1 : pix == HESS_PIX_U16 ? 2 : 4; }
+
+// Option key: the first up to four characters, lower-cased (STRING_TO_INT, SiftGPU.cpp:857-860).
+std::string opt_key(const char* opt) {
+  std::string k;
+  for (int i = 0; i < 4 && opt[i]; i++) k.push_back((char)tolower((unsigned char)opt[i]));
+  return k;
+}
+
+// Built-in PNM loader (the reference's SIFTGPU_NO_DEVIL path, GLTexImage.cpp:1159-1220): P2/P3/P5/P6,
+// colour files reduced with its PNM-specific weights int(0.10454 B + 0.60581 G + 0.28965 R).
+bool load_pnm(const char* path, std::vector<unsigned char>& out, int& w, int& h) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  char magic[8] = {0};
+  int cn = 0;
+  if (fscanf(f, "%7s %d %d %d", magic, &w, &h, &cn) < 4 || cn > 255 || w <= 0 || h <= 0) { fclose(f); return false; }
+  out.assign((size_t)w * h, 0);
+  bool ok = true;
+  if (!strcmp(magic, "P5")) {
+    fgetc(f);
+    ok = fread(out.data(), 1, out.size(), f) == out.size();
+  } else if (!strcmp(magic, "P2")) {
+    for (size_t i = 0; i < out.size() && ok; i++) { int g; ok = fscanf(f, "%d", &g) == 1; out[i] = (unsigned char)g; }
+  } else if (!strcmp(magic, "P6")) {
+    fgetc(f);
+    unsigned char rgb[3];
+    for (size_t i = 0; i < out.size() && ok; i++) {
+      ok = fread(rgb, 1, 3, f) == 3;
+      out[i] = (unsigned char)int(0.10454f * rgb[2] + 0.60581f * rgb[1] + 0.28965f * rgb[0]);
+    }
+  } else if (!strcmp(magic, "P3")) {
+    for (size_t i = 0; i < out.size() && ok; i++) {
+      int r, g, b;
+      ok = fscanf(f, "%d %d %d", &r, &g, &b) == 3;
+      out[i] = (unsigned char)int(0.10454f * b + 0.60581f * g + 0.28965f * r);
+    }
+  } else {
+    ok = false;
+  }
+  fclose(f);
+  return ok;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// SiftParam: SiftGPU.cpp:466-563, 1422-1425
+
+SiftParam::SiftParam() {
+  _sigma = nullptr;
+  _sigma_skip0 = _sigma_skip1 = 0;
+  _sigma_num = 0;
+  _level_min = 0;
+  _dog_level_num = 3;
+  _level_num = 0;
+  _level_max = 0;
+  _level_ds = 0;
+  _sigma0 = 0;
+  _sigman = 0;
+  _edge_threshold = 0;
+  _dog_threshold = 0;
+}
+
+float SiftParam::GetInitialSmoothSigma(int octave_min) {
+  float sa = _sigma0 * powf(2.0f, float(_level_min) / float(_dog_level_num));
+  float sb = _sigman / powf(2.0f, float(octave_min));
+  return (sa > sb + 0.001) ? sqrtf(sa * sa - sb * sb) : 0.0f;
+}
+
+float SiftParam::GetLevelSigma(int lev) { return _sigma0 * powf(2.0f, float(lev) / float(_dog_level_num)); }
+
+void SiftParam::ParseSiftParam() {
+  if (_dog_level_num == 0) _dog_level_num = 3;
+  if (_level_max == 0) _level_max = _dog_level_num + 1;
+  if (_sigma0 == 0.0f) _sigma0 = 1.6f;
+  if (_sigman == 0.0f) _sigman = 0.5f;
+  _level_num = _level_max - _level_min + 1;
+  _level_ds = _level_min + _dog_level_num;
+  if (_level_ds > _level_max) _level_ds = _level_max;
+  const float sigmak = powf(2.0f, 1.0f / _dog_level_num);
+  const float dsigma0 = _sigma0 * sqrtf(sigmak * sigmak - 1.0f);
+  float sa = _sigma0 * powf(sigmak, (float)_level_min);
+  float sb = _sigman;  // first octave 0
+  _sigma_skip0 = (sa > sb + 0.001) ? sqrtf(sa * sa - sb * sb) : 0.0f;
+  sb = _sigma0 * powf(sigmak, float(_level_ds - _dog_level_num));
+  _sigma_skip1 = (sa > sb + 0.001) ? sqrtf(sa * sa - sb * sb) : 0.0f;
+  _sigma_num = _level_max - _level_min;
+  delete[] _sigma;
+  _sigma = new float[_sigma_num];
+  for (int i = _level_min + 1; i <= _level_max; i++)
+    _sigma[i - (_level_min + 1)] = dsigma0 * powf(sigmak, float(i - (_level_min + 1)));
+  if (_dog_threshold == 0) _dog_threshold = 0.02f / _dog_level_num;
+  if (_edge_threshold == 0) _edge_threshold = 10.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SiftGPU
+
+SiftGPU::SiftGPU(int np) {
+  (void)np;
+  _texImage = nullptr;
+  _list = nullptr;
+  _imgpath = new char[4096];
+  _outpath = new char[4096];
+  _imgpath[0] = _outpath[0] = 0;
+  _initialized = 0;
+  _image_loaded = 0;
+  _current = 0;
+  Impl* im = new Impl();
+  hess_default_params(&im->p);
+  _pyramid = reinterpret_cast<SiftPyramid*>(im);
+  memset(_timing, 0, sizeof(_timing));
+}
+
+SiftGPU::~SiftGPU() {
+  Impl* im = I(_pyramid);
+  if (im) {
+    if (im->ctx) hess_destroy(im->ctx);
+    delete im;
+  }
+  delete[] _imgpath;
+  delete[] _outpath;
+  delete[] _sigma;
+}
+
+void* SiftGPU::operator new(size_t size) {  // SiftGPU.cpp:116-125: heap allocation inside the library
+  void* p = malloc(size);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+
+void SiftGPU::PrintUsage() {
+  std::cout << "SiftGPU (MI355X HessGPU build) options:\n"
+               "-i <files..> -il <listfile> -o <out>     input images / image list / output file\n"
+               "-t <f> -e <f> -d <n> -fo <n> -no <n>     threshold, edge threshold, scales per octave, first octave, octaves\n"
+               "-f <f> -w <f> -dw <f>                    filter width, orientation window, descriptor window factors\n"
+               "-m [n] -s [n] -ofix -ofix-not -loweo     orientations, sub-pixel, fixed orientation, Lowe origin\n"
+               "-topk <n> -tc/-tc1/-tc2/-tc3 <n>         limit the number of features\n"
+               "-half -sd -b -bvlf -ads -maxd <n> -p WxH -tight -cuda <dev> -v <0..4>\n";
+}
+
+void SiftGPU::SetVerbose(int verbose) {  // SiftGPU.cpp:433-464
+  Impl* im = I(_pyramid);
+  im->timingO = (verbose > 2);
+  im->timingL = (verbose > 3);
+  if (verbose == -1) {
+    if (im->verbose) { im->verbose = im->timingS; im->timingS = 0; }
+    else { im->verbose = 1; im->timingS = 1; }
+  } else if (verbose == -2) {
+    im->verbose = 0;
+    im->timingS = 1;
+  } else {
+    im->verbose = (verbose > 0);
+    im->timingS = (verbose > 1);
+  }
+}
+
+void SiftGPU::ParseParam(int argc, char** argv) {  // SiftGPU.cpp:855-1380
+  Impl* im = I(_pyramid);
+  hess_params& p = im->p;
+  for (int i = 0; i < argc; i++) {
+    const char* arg = argv[i];
+    if (!arg || arg[0] != '-' || !arg[1]) continue;
+    const char* opt = arg + 1;
+    const std::string k = opt_key(opt);
+    const char* param = (i + 1 < argc) ? argv[i + 1] : nullptr;
+    im->dirty = true;
+    // ---- options without a mandatory value ----
+    if (k == "h" || k == "help") { PrintUsage(); continue; }
+    if (k == "cuda") {
+      if (!_initialized) {
+        int device = -1;
+        if (param && sscanf(param, "%d", &device) && device >= 0) { im->device = device; i++; }
+      }
+      continue;
+    }
+    if (k == "lcpu" || k == "lc" || k == "prep" || k == "nopr" || k == "exit" || k == "di" || k == "debu" ||
+        k == "k0" || k == "kx" || k == "da" || k == "fmc" || k == "nomc")
+      continue;  // accepted, no effect on this backend
+    if (k == "sd") { if (!_initialized) p.compute_descriptors = 0; continue; }
+    if (k == "b") { im->binary_sift = 1; continue; }
+    if (k == "ads") { p.auto_downscale = 1; continue; }
+    if (k == "bvlf") { im->binary_sift = 2; continue; }
+    if (k == "half") { p.half_sift = 1; continue; }
+    if (k == "tigh") { im->tight = 1; continue; }
+    if (k == "m" || k == "mo") {
+      if (!_initialized) {
+        int mo = 2;
+        if (param) sscanf(param, "%d", &mo);
+        p.max_orientation = mo < 1 ? 1 : (mo > 4 ? 4 : mo);
+      }
+      continue;  // the value is read but not consumed (SiftGPU.cpp:1039-1049)
+    }
+    if (k == "s") {
+      if (!_initialized) {
+        int sp = 1;
+        if (param) sscanf(param, "%d", &sp);
+        p.subpixel = sp < 0 ? 0 : (sp > 5 ? 5 : sp);
+      }
+      continue;
+    }
+    if (k == "ofix") { p.fixed_orientation = (strcasecmp(opt, "ofix") == 0); continue; }
+    if (k == "lowe") { p.lowe_origin = 1; continue; }
+    // ---- options that need a value ----
+    if (!param) continue;
+    if (k == "i") {
+      strcpy(_imgpath, param);
+      i++;
+      im->list.push_back(param);
+      while (i + 1 < argc && argv[i + 1][0] != '-') im->list.push_back(argv[++i]);
+    } else if (k == "il") {
+      LoadImageList(param);
+      i++;
+    } else if (k == "o") {
+      strcpy(_outpath, param);
+      i++;
+    } else if (k == "f") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0) { p.filter_width_factor = v; i++; }
+    } else if (k == "ot") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0) i++;  // parsed; the kernel constant is 0.8
+    } else if (k == "w") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0) { p.orient_window_factor = v; i++; }
+    } else if (k == "dw") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0) { p.desc_window_factor = v; i++; }
+    } else if (k == "fo") {
+      int v = -3; if (sscanf(param, "%d", &v) && v >= 0) { p.first_octave = v; i++; }
+    } else if (k == "no") {
+      if (!_initialized) {
+        int v = -1;
+        if (sscanf(param, "%d", &v)) { if (v < -1) v = -1; if (v == -1 || v >= 1) { p.octave_num = v; i++; } }
+      }
+    } else if (k == "t") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0 && v < 0.5f) { _dog_threshold = v; i++; }
+    } else if (k == "e") {
+      float v = 0; if (sscanf(param, "%f", &v) && v > 0) { _edge_threshold = v; i++; }
+    } else if (k == "d") {
+      int v = 0; if (sscanf(param, "%d", &v) && v >= 1 && v <= 10) { _dog_level_num = v; i++; }
+    } else if (k == "fs" || k == "lm" || k == "lmp" || k == "winp" || k == "disp") {
+      i++;  // storage-block / window options of other backends
+    } else if (k == "p") {
+      int w = 0, h = 0;
+      if (sscanf(param, "%dx%d", &w, &h) == 2 && w > 0 && h > 0) { im->init_w = w; im->init_h = h; i++; }
+    } else if (k == "tc" || k == "tc1" || k == "tc2" || k == "tc3" || k == "topk") {
+      p.truncate_method = (k == "tc2") ? HESS_TRUNC_HIGHEST_1 : (k == "tc3") ? HESS_TRUNC_LOWEST
+                          : (k == "topk") ? HESS_TRUNC_TOPK : HESS_TRUNC_HIGHEST_0;
+      int v = -1;
+      if (sscanf(param, "%d", &v) && v > 0) { p.feature_count_threshold = v; i++; }
+    } else if (k == "v") {
+      int v = 0; if (sscanf(param, "%d", &v) && v >= 0 && v <= 4) SetVerbose(v);
+    } else if (k == "maxd") {
+      int v = 0; if (sscanf(param, "%d", &v) && v > 0) p.tex_max_dim = v;
+    } else if (k == "mind") {
+      // parsed; the CUDA backend of the reference never reads _texMinDim
+    }
+  }
+  if (_outpath[0] && im->list.size() > 1) _outpath[0] = 0;  // SiftGPU.cpp:1377-1379
+}
+
+void SiftGPU::SetImageList(int nimage, const char** filelist) {
+  Impl* im = I(_pyramid);
+  im->list.clear();
+  for (int i = 0; i < nimage; i++) im->list.push_back(filelist[i]);
+  _current = 0;
+}
+
+void SiftGPU::LoadImageList(const char* imlist) {  // SiftGPU.cpp:1394-1420
+  Impl* im = I(_pyramid);
+  std::ifstream in(imlist);
+  std::string name;
+  while (in >> name) im->list.push_back(name);
+  if (!im->list.empty()) {
+    strcpy(_imgpath, im->list[0].c_str());
+    std::string dir(imlist);
+    size_t slash = dir.find_last_of("\\/");
+    if (slash != std::string::npos) {
+      dir.resize(slash + 1);
+      if (chdir(dir.c_str()) != 0 && im->verbose) std::cerr << "cannot chdir to " << dir << "\n";
+    }
+  }
+  _image_loaded = 0;
+}
+
+int SiftGPU::GetImageCount() { return (int)I(_pyramid)->list.size(); }
+void SiftGPU::SetTightPyramid(int tight) { I(_pyramid)->tight = tight; }
+void SiftGPU::SetMaxDimension(int sz) { if (sz > 0) { I(_pyramid)->p.tex_max_dim = sz; I(_pyramid)->dirty = true; } }
+
+// InitSiftGPU (SiftGPU.cpp:149-227): resolve the schedule and (re)create the device context.
+void SiftGPU::InitSiftGPU() {
+  Impl* im = I(_pyramid);
+  if (_initialized && !im->dirty && im->ctx) return;
+  ParseSiftParam();
+  hess_params p = im->p;
+  p.dog_level_num = _dog_level_num;
+  p.sigma0 = _sigma0;
+  p.sigman = _sigman;
+  p.dog_threshold = _dog_threshold;
+  p.edge_threshold = _edge_threshold;
+  p.verbose = im->verbose;
+  if (im->ctx) { hess_destroy(im->ctx); im->ctx = nullptr; }
+  im->ctx = hess_create(im->device, &p);
+  im->p = p;
+  im->dirty = false;
+  _initialized = 1;
+  if (im->ctx && im->init_w > 0 && im->init_h > 0) hess_reserve(im->ctx, im->init_w, im->init_h, 1);
+}
+
+int SiftGPU::CreateContextGL() { return VerifyContextGL(); }  // SiftGPU.cpp:1516-1539
+
+int SiftGPU::VerifyContextGL() {
+  InitSiftGPU();
+  return I(_pyramid)->ctx ? SIFTGPU_FULL_SUPPORTED : SIFTGPU_NOT_SUPPORTED;
+}
+
+int SiftGPU::IsFullSupported() { return I(_pyramid)->ctx != nullptr; }
+
+int SiftGPU::AllocatePyramid(int width, int height) {
+  InitSiftGPU();
+  Impl* im = I(_pyramid);
+  return im->ctx && hess_reserve(im->ctx, width, height, 1) == 0;
+}
+
+int SiftGPU::RunSIFT(int index) {  // SiftGPU.cpp:229-246
+  Impl* im = I(_pyramid);
+  if (im->list.empty()) return 0;
+  index = index % (int)im->list.size();
+  if (strcmp(_imgpath, im->list[index].c_str())) {
+    strcpy(_imgpath, im->list[index].c_str());
+    _image_loaded = 0;
+    _current = index;
+  }
+  return RunSIFT();
+}
+
+int SiftGPU::RunSIFT(const char* imgpath) {  // SiftGPU.cpp:292-305
+  if (!imgpath || !imgpath[0]) return 0;
+  strcpy(_imgpath, imgpath);
+  _image_loaded = 0;
+  return RunSIFT();
+}
+
+int SiftGPU::RunSIFT(int width, int height, const void* data, unsigned int gl_format, unsigned int gl_type) {
+  // SiftGPU.cpp:248-290 -> GLTexInput::SetImageData
+  Impl* im = I(_pyramid);
+  int fmt, pix;
+  if (width <= 0 || height <= 0 || !data) return 0;
+  if (!gl_to_hess(gl_format, gl_type, &fmt, &pix)) {
+    std::cerr << "Input format not supported under current settings.\n";
+    return 0;
+  }
+  const size_t bytes = (size_t)width * height * channels(fmt) * pix_bytes(pix);
+  im->pixels.assign((const unsigned char*)data, (const unsigned char*)data + bytes);
+  im->w = width; im->h = height; im->fmt = fmt; im->pix = pix;
+  _imgpath[0] = 0;
+  _image_loaded = 2;
+  return RunSIFT();
+}
+
+int SiftGPU::RunSIFT(int num, const SiftKeypoint* keys, int keys_have_orientation) {
+  SetKeypointList(num, keys, keys_have_orientation);
+  return 0;
+}
+
+void SiftGPU::SetKeypointList(int num, const SiftKeypoint* keys, int keys_have_orientation) {
+  (void)num; (void)keys; (void)keys_have_orientation;
+  Impl* im = I(_pyramid);
+  if (!im->warned_keylist) {
+    std::cerr << "SiftGPU: user-supplied keypoint lists are not implemented in this build\n";
+    im->warned_keylist = true;
+  }
+}
+
+int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
+  Impl* im = I(_pyramid);
+  if (_imgpath[0] == 0 && _image_loaded == 0) return 0;
+  InitSiftGPU();
+  if (!im->ctx) return 0;
+  memset(_timing, 0, sizeof(_timing));
+  if (_image_loaded == 0) {
+    if (!load_pnm(_imgpath, im->pixels, im->w, im->h)) {
+      std::cerr << "Unable to open image (this build reads PGM/PPM only): " << _imgpath << "\n";
+      return 0;
+    }
+    im->fmt = HESS_FMT_LUM;
+    im->pix = HESS_PIX_U8;
+    if (im->verbose) std::cout << "Image loaded :\t" << _imgpath << "\n";
+  }
+  _image_loaded = 1;
+  const int pitch = im->w * channels(im->fmt) * pix_bytes(im->pix);
+  const int rc = hess_run_host(im->ctx, im->pixels.data(), im->w, im->h, pitch, (size_t)pitch * im->h, 1, im->fmt, im->pix);
+  if (rc != 0) {
+    std::cerr << "SiftGPU: " << hess_last_error(im->ctx) << "\n";
+    im->nfeat = 0;
+    return 0;  // device errors -> 0 (SiftPyramid.h:162-163); oversize image is an error return here, not exit()
+  }
+  im->nfeat = hess_count(im->ctx, 0);
+  im->dim = hess_desc_dim(im->ctx);
+  im->keys.resize(im->nfeat ? im->nfeat : 1);
+  im->desc.resize((size_t)(im->nfeat ? im->nfeat : 1) * (im->dim ? im->dim : 1));
+  hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
+  const float* t = hess_timing(im->ctx);
+  for (int k = 0; k < 12; k++) _timing[k] = t[k];
+  if (im->verbose) {
+    std::cout << "#Features:\t" << im->nfeat << "\n";
+    if (im->timingS) std::cout << "RUN SIFT:\t" << _timing[TIMINGS_TOTAL] << "ms\n";
+    std::cout << std::endl;
+  }
+  if (_outpath[0]) { SaveSIFT(_outpath); _outpath[0] = 0; }
+  return 1;
+}
+
+int SiftGPU::GetFeatureNum() { return I(_pyramid)->nfeat; }
+
+void SiftGPU::GetFeatureVector(SiftKeypoint* keys, float* descriptors) {  // SiftPyramid.cpp:313-324
+  Impl* im = I(_pyramid);
+  static_assert(sizeof(SiftKeypoint) == sizeof(hess_keypoint), "keypoint layout");
+  if (keys && im->nfeat) memcpy(keys, im->keys.data(), (size_t)im->nfeat * sizeof(SiftKeypoint));
+  // The reference always copies 128*n floats, over-reading its 64*n buffer in -half mode; here dim*n.
+  if (descriptors && im->dim && im->nfeat) memcpy(descriptors, im->desc.data(), (size_t)im->nfeat * im->dim * sizeof(float));
+}
+
+void SiftGPU::SaveSIFT(const char* szFileName) {  // SiftPyramid::SaveSIFT, SiftPyramid.cpp:357-571
+  Impl* im = I(_pyramid);
+  if (im->nfeat <= 0) return;
+  const int n = im->nfeat, dim = im->dim;
+  const hess_keypoint* pk = im->keys.data();
+  const float* pd = im->desc.data();
+  if (im->binary_sift == 2) {  // vlfeat-style binary
+    std::ofstream out(szFileName, std::ios::binary);
+    out.write("aff\1", 4);
+    out.write((const char*)&n, sizeof(int));
+    out.write((const char*)&dim, sizeof(int));
+    int iw = im->w >> 0, ih = im->h;
+    out.write((const char*)&iw, sizeof(int));
+    out.write((const char*)&ih, sizeof(int));
+    for (int i = 0; i < n; i++, pk++) {
+      const unsigned int lt = ((unsigned)pk->level << 2) | pk->type;
+      const float scale = pk->s * im->mr_size;
+      const float a11 = cosf(pk->o), a12 = -sinf(pk->o), a21 = sinf(pk->o), a22 = cosf(pk->o);
+      out.write((const char*)&pk->x, 4); out.write((const char*)&pk->y, 4); out.write((const char*)&scale, 4);
+      out.write((const char*)&a11, 4); out.write((const char*)&a12, 4); out.write((const char*)&a21, 4); out.write((const char*)&a22, 4);
+      out.write((const char*)&lt, 4);
+      out.write((const char*)&pk->response, 4);
+      for (int k = 0; k < dim; k++, pd++) {
+        const unsigned char v = (unsigned char)floor(0.5f + 255.0f * (*pd));
+        out.write((const char*)&v, 1);
+      }
+    }
+  } else if (im->binary_sift) {
+    std::ofstream out(szFileName, std::ios::binary);
+    out.write((const char*)&n, sizeof(int));
+    out.write((const char*)&dim, sizeof(int));
+    for (int i = 0; i < n; i++, pk++) {
+      out.write((const char*)&pk->y, 4); out.write((const char*)&pk->x, 4);
+      out.write((const char*)&pk->s, 4); out.write((const char*)&pk->o, 4);
+      out.write((const char*)&pk->response, 4);
+      out.write((const char*)&pk->type, 2); out.write((const char*)&pk->level, 2);
+      if (dim) { out.write((const char*)pd, dim * sizeof(float)); pd += dim; }
+    }
+  } else {
+    std::ofstream out(szFileName);
+    out.flags(std::ios::fixed);
+    out << n << " " << dim << std::endl;
+    for (int i = 0; i < n; i++, pk++) {
+      out << std::setprecision(2) << pk->y << " " << std::setprecision(2) << pk->x << " "
+          << std::setprecision(3) << pk->s << " " << std::setprecision(3) << pk->o;
+      out << " " << std::setprecision(8) << pk->response;
+      out << " " << pk->type << " " << pk->level;
+      out << std::endl;
+      if (dim) {
+        for (int k = 0; k < dim; k++, pd++) {
+          if (im->p.normalize) out << ((unsigned int)floor(0.5 + 512.0f * (*pd))) << " ";
+          else out << std::setprecision(8) << pd[0] << " ";
+          if ((k + 1) % 20 == 0) out << std::endl;
+        }
+        out << std::endl;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matcher / combo classes: declared for source compatibility, not implemented (out of the hot path).
+
+static void matcher_notice() {
+  static bool said = false;
+  if (!said) { std::cerr << "SiftMatchGPU is not implemented in this build\n"; said = true; }
+}
+SiftMatchGPU::SiftMatchGPU(int max_sift) : __max_sift(max_sift), __language(0), __matcher(nullptr) {}
+SiftMatchGPU::~SiftMatchGPU() {}
+int SiftMatchGPU::_CreateContextGL() { matcher_notice(); return 0; }
+int SiftMatchGPU::_VerifyContextGL() { matcher_notice(); return 0; }
+void SiftMatchGPU::SetLanguage(int language) { __language = language; }
+void SiftMatchGPU::SetDeviceParam(int, char**) {}
+void SiftMatchGPU::SetMaxSift(int max_sift) { __max_sift = max_sift; }
+void SiftMatchGPU::SetDescriptors(int, int, const float*, int) { matcher_notice(); }
+void SiftMatchGPU::SetDescriptors(int, int, const unsigned char*, int) { matcher_notice(); }
+int SiftMatchGPU::GetSiftMatch(int, int[][2], float, float, int) { matcher_notice(); return 0; }
+void SiftMatchGPU::SetFeautreLocation(int, const float*, int) { matcher_notice(); }
+int SiftMatchGPU::GetGuidedSiftMatch(int, int[][2], float[3][3], float[3][3], float, float, float, float, int) {
+  matcher_notice();
+  return 0;
+}
+void* SiftMatchGPU::operator new(size_t size) {
+  void* p = malloc(size);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void* ComboSiftGPU::operator new(size_t size) {
+  void* p = malloc(size);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factories (SiftGPU.h:364-379) and the flat C mirror.
+
+extern "C" {
+
+SiftGPU* CreateNewSiftGPU(int np) { return new SiftGPU(np); }
+SiftMatchGPU* CreateNewSiftMatchGPU(int) { matcher_notice(); return nullptr; }
+ComboSiftGPU* CreateComboSiftGPU() { return nullptr; }
+ComboSiftGPU* CreateRemoteSiftGPU(int, char*) { return nullptr; }
+
+void siftgpu_destroy(SiftGPU* s) { delete s; }
+void siftgpu_parse_param(SiftGPU* s, int argc, char** argv) { s->ParseParam(argc, argv); }
+int siftgpu_create_context(SiftGPU* s) { return s->CreateContextGL(); }
+int siftgpu_run_data(SiftGPU* s, int w, int h, const void* data, unsigned f, unsigned t) { return s->RunSIFT(w, h, data, f, t); }
+int siftgpu_run_file(SiftGPU* s, const char* path) { return s->RunSIFT(path); }
+int siftgpu_run_index(SiftGPU* s, int index) { return s->RunSIFT(index); }
+int siftgpu_feature_num(SiftGPU* s) { return s->GetFeatureNum(); }
+void siftgpu_feature_vector(SiftGPU* s, SiftGPU::SiftKeypoint* keys, float* desc) { s->GetFeatureVector(keys, desc); }
+void siftgpu_save(SiftGPU* s, const char* path) { s->SaveSIFT(path); }
+const float* siftgpu_timing(SiftGPU* s) { return s->_timing; }
+void siftgpu_set_verbose(SiftGPU* s, int v) { s->SetVerbose(v); }
+int siftgpu_image_count(SiftGPU* s) { return s->GetImageCount(); }
+
+}  // extern "C"
+
+// siftgpu_get_params / siftgpu_descriptor_dim need the protected _pyramid: a friend-free accessor.
+namespace {
+struct Peek : SiftGPU {
+  static Impl* impl(SiftGPU* s) { return I(static_cast<Peek*>(s)->_pyramid); }
+  static void sync(SiftGPU* s) {
+    Peek* p = static_cast<Peek*>(s);
+    Impl* im = I(p->_pyramid);
+    SiftParam tmp;
+    tmp._dog_level_num = p->_dog_level_num; tmp._sigma0 = p->_sigma0; tmp._sigman = p->_sigman;
+    tmp._dog_threshold = p->_dog_threshold; tmp._edge_threshold = p->_edge_threshold;
+    tmp.ParseSiftParam();
+    im->p.dog_level_num = tmp._dog_level_num; im->p.sigma0 = tmp._sigma0; im->p.sigman = tmp._sigman;
+    im->p.dog_threshold = tmp._dog_threshold; im->p.edge_threshold = tmp._edge_threshold;
+    delete[] tmp._sigma;
+    tmp._sigma = nullptr;
+  }
+};
+}  // namespace
+
+extern "C" int siftgpu_get_params(SiftGPU* s, void* out) {
+  if (!s || !out) return -1;
+  Peek::sync(s);
+  memcpy(out, &Peek::impl(s)->p, sizeof(hess_params));
+  return 0;
+}
+extern "C" int siftgpu_descriptor_dim(SiftGPU* s) { return s ? Peek::impl(s)->dim : -1; }

@@ -1,0 +1,96 @@
+"""The SiftGPU C++ class end to end on the GPU: RunSIFT / GetFeatureNum / GetFeatureVector /
+SaveSIFT through libsiftgpu.so, compared with the oracle."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import fixtures
+import siftgpu_lib
+from oracle_lib import OracleSession
+
+pytestmark = pytest.mark.gpu
+
+
+def test_runsift_rgb_matches_oracle():
+    img = fixtures.load_rgb("640-1.jpg")
+    s = siftgpu_lib.SiftGPU([])
+    assert s.create_context() == 2  # SIFTGPU_FULL_SUPPORTED
+    assert s.run(img, siftgpu_lib.GL_RGB, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    k, d = s.features()
+    o = OracleSession(threads=8, keep_levels=False)
+    o.run(img[None])
+    ok, od = o.fetch(0)
+    assert k.tobytes() == ok.tobytes() and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    t = s.timing()
+    assert t[11] > 0 and t[2] > 0  # TIMINGS_TOTAL, TIMINGS_BUILD_PYRAMID
+    s.close()
+
+
+def test_parse_param_drives_the_path(tmp_path):
+    img = fixtures.load_rgb("640-2.jpg")
+    s = siftgpu_lib.SiftGPU(["-topk", "200", "-half", "-t", "0.005"])
+    assert s.run(img, siftgpu_lib.GL_RGB, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    k, d = s.features()
+    o = OracleSession(threads=8, keep_levels=False, truncate_method=3, feature_count_threshold=200, half_sift=1,
+                      dog_threshold=0.005)
+    o.run(img[None])
+    ok, od = o.fetch(0)
+    assert d.shape[1] == 64 and k.tobytes() == ok.tobytes() and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    # options marked * can change after initialisation
+    s.parse(["-topk", "50"])
+    assert s.run(img, siftgpu_lib.GL_RGB, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    assert len(np.unique(np.stack([s.features()[0]["x"], s.features()[0]["y"]]), axis=1).T) == 50
+    s.close()
+
+
+def test_pgm_file_and_save_formats(tmp_path):
+    lum = fixtures.load_rgb("640-3.jpg")[..., 1].copy()
+    pgm = tmp_path / "img.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (lum.shape[1], lum.shape[0]))
+        f.write(lum.tobytes())
+    s = siftgpu_lib.SiftGPU([])
+    assert s.run_file(str(pgm)) == 1
+    k, d = s.features()
+    o = OracleSession(threads=8, keep_levels=False)
+    o.run(lum[None])
+    ok, od = o.fetch(0)
+    assert k.tobytes() == ok.tobytes() and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    # text format (SiftPyramid.cpp:504-566)
+    txt = tmp_path / "out.sift"
+    s.save(str(txt))
+    tok = open(txt).read().split()
+    n, dim = int(tok[0]), int(tok[1])
+    assert n == len(k) and dim == 128
+    rec = tok[2:2 + 7 + 128]
+    assert abs(float(rec[0]) - k["y"][0]) < 0.006 and abs(float(rec[1]) - k["x"][0]) < 0.006
+    assert int(rec[5]) == k["type"][0] and int(rec[6]) == k["level"][0]
+    assert [int(v) for v in rec[7:]] == [int(np.floor(0.5 + 512.0 * v)) for v in d[0]]
+    # binary format (SiftPyramid.cpp:453-502)
+    s.parse(["-b"])
+    binp = tmp_path / "out.bin"
+    s.save(str(binp))
+    raw = open(binp, "rb").read()
+    nb, db = struct.unpack("<ii", raw[:8])
+    assert (nb, db) == (n, 128) and len(raw) == 8 + n * (24 + 512)
+    y, x, sc, ori, resp, typ, lvl = struct.unpack("<fffffHH", raw[8:32])
+    assert (x, y, sc, ori, resp, typ, lvl) == tuple(k[f][0] for f in ("x", "y", "s", "o", "response", "type", "level"))
+    assert np.array_equal(np.frombuffer(raw[32:32 + 512], np.float32), d[0])
+    # vlfeat-style format (SiftPyramid.cpp:372-448)
+    s.parse(["-bvlf"])
+    vl = tmp_path / "out.vlf"
+    s.save(str(vl))
+    raw = open(vl, "rb").read()
+    assert raw[:4] == b"aff\x01" and struct.unpack("<iiii", raw[4:20]) == (n, 128, 640, 480)
+    assert len(raw) == 20 + n * (9 * 4 + 128)
+    s.close()
+
+
+def test_oversize_image_returns_zero_not_exit():
+    s = siftgpu_lib.SiftGPU([])
+    assert s.run(np.zeros((8, 3300), np.uint8), siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 0
+    s.parse(["-maxd", "4096"])
+    assert s.run(np.zeros((8, 3300), np.uint8), siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    s.close()
