@@ -29,6 +29,8 @@ struct OctGeom {
   long long got_off;    // element offset of [octave][1][0] in got (units: float2)
   int row_base;         // first row index of this octave in the per-image row order
   int mask_base;        // first mask word of this octave in the per-image mask array
+  int tiles_x;          // extrema tiles (256 x 8 px) per row of tiles
+  int tile_base;        // first extrema tile of this octave in the per-image tile order
 };
 
 struct Geom {
@@ -36,6 +38,7 @@ struct Geom {
   int B;                // batch capacity the planes are laid out for
   int NR;               // rows per image in list order: dog * sum_o h_o
   int NM;               // mask words per image
+  int ntiles;           // extrema tiles per image
   OctGeom o[kMaxOct];
 };
 
@@ -121,7 +124,7 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
 // Extrema scan, pass 2: ordered scatter of the detections into the raw list.
 void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                             const float* deth, const uint64_t* rowmask, const int* rowoff,
-                            RawKey* raw, int cap_raw, int batch);
+                            const int* raw_total, RawKey* raw, int cap_raw, int batch);
 
 // Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
 // the lower list index, order preserved.  sel may alias nothing; when total < K the list is copied.

@@ -263,6 +263,9 @@ int plan(hess_ctx* c, int width, int height, int batch) {
     og.got_off = gt;
     og.row_base = rows;
     og.mask_base = mw;
+    og.tiles_x = (og.wa + 255) / 256;
+    og.tile_base = g.ntiles;
+    g.ntiles += og.tiles_x * ((og.h + 3) / 4);  // EX_TR rows per extrema tile (k_detect.hip)
     lvl += (long long)c->sch.level_num * B * og.plane;
     gt += (long long)g.dog * B * og.plane;
     rows += g.dog * og.h;
@@ -440,7 +443,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   {
     ProfScope ps(c, HESS_K_EXTREMA, 0.0);
     launch_extrema_scatter(st, g, dp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowoff.p,
-                           (RawKey*)c->raw.p, c->cap_raw, batch);
+                           (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch);
   }
   (void)hipEventRecord(c->ev[3], st);
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----

@@ -115,6 +115,9 @@ struct KeyVal {
 
 // ComputeKEY_Kernel body for one interior pixel (ProgramCU.cu:725-857).  The comparison macro
 // re-selects its branch per triple with the running nmax exactly as READ_CMP_DOG_DATA does.
+// PRE = true stops after the 26-neighbour and edge tests (everything before the sub-pixel solve) and
+// reports whether the pixel is still a candidate; the arithmetic is the same code either way.
+template <bool PRE = false>
 __device__ __forceinline__ bool key_eval(const float* texC, const float* texP, const float* texN,
                                          const float* texG, int width, int index, const DetectParams& dp,
                                          KeyVal* out) {
@@ -151,6 +154,7 @@ __device__ __forceinline__ bool key_eval(const float* texC, const float* texP, c
   HESS_READ_CMP(n10, n11, n12, texN, i1);
   HESS_READ_CMP(n20, n21, n22, texN, i2);
   (void)p00; (void)p02; (void)p20; (void)p22; (void)n00; (void)n02; (void)n20; (void)n22;
+  if (PRE) return true;
 
   if (dp.subpixel) {  // ProgramCU.cu:769-825
     const float fx = 0.5f * (d12 - d10);
@@ -221,65 +225,176 @@ __device__ __forceinline__ RowTask decode_row(const Geom& g, int wave, int batch
   return t;
 }
 
-__global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* gauss,
-                                                           const float* deth, uint64_t* rowmask, int* rowcnt,
-                                                           int batch) {
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  RowTask t = decode_row(g, wave, batch);
-  if (!t.valid) return;
-  const OctGeom& og = g.o[t.o];
-  const long long poff = og.lvl_off + ((long long)t.l * g.B + t.b) * og.plane;
-  const long long lstep = (long long)g.B * og.plane;
-  const float* C = deth + poff;
-  uint64_t* mrow = rowmask + (long long)t.b * g.NM + og.mask_base + ((t.l - 1) * og.h + t.row) * og.w64;
-  const bool row_ok = (t.row > 0) && (t.row < og.h - 1);
-  int cnt = 0;
-  for (int wd = 0; wd < og.w64; wd++) {
-    const int col = wd * 64 + lane;
-    bool flag = false;
-    if (row_ok && col > 0 && col < og.wa - 1)
-      flag = key_eval(C, C - lstep, C + lstep, gauss + poff, og.wa, t.row * og.wa + col, dp, nullptr);
-    const uint64_t m = __ballot(flag);
-    if (lane == 0) mrow[wd] = m;
-    cnt += __popcll(m);
-  }
-  if (lane == 0) rowcnt[wave] = cnt;
-}
+// Extrema scan pass 1, LDS-tiled: one workgroup stages a (8+2) x (256+8) window of ALL dog+2 det-H
+// levels of one octave (each level-pixel fetched from HBM once, 16-byte loads).  Per detection level:
+//   stage 1  every pixel of the tile runs the cheap part of the test (thresholds, 26 neighbours, edge
+//            ratio) from LDS, 64 pixels per wavefront step; survivors are appended to an LDS queue;
+//   stage 2  the queue is processed one candidate per lane, so the expensive sub-pixel solve
+//            (9 IEEE divisions) runs with full lanes instead of 1-2 live lanes per wavefront;
+//            accepted pixels set their bit in the tile's mask words (LDS atomicOr);
+// then the mask words and per-row counts go to HBM.  Bits are positional, so the list order produced
+// by the scatter pass is independent of the order candidates were queued in.
+constexpr int EX_TR = 4, EX_TC = 256, EX_STRIDE = EX_TC + 8 + 4;  // cols x0-4 .. x0+260, +4 pad
 
-__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, const float* gauss,
-                                                              const float* deth, const uint64_t* rowmask,
-                                                              const int* rowoff, RawKey* raw, int cap_raw,
-                                                              int batch) {
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  RowTask t = decode_row(g, wave, batch);
-  if (!t.valid) return;
-  int base = rowoff[wave];
-  if (base < 0) return;  // level dropped by -tc
-  const OctGeom& og = g.o[t.o];
-  const long long poff = og.lvl_off + ((long long)t.l * g.B + t.b) * og.plane;
-  const long long lstep = (long long)g.B * og.plane;
-  const float* C = deth + poff;
-  const uint64_t* mrow = rowmask + (long long)t.b * g.NM + og.mask_base + ((t.l - 1) * og.h + t.row) * og.w64;
-  RawKey* out = raw + (long long)t.b * cap_raw;
-  for (int wd = 0; wd < og.w64; wd++) {
-    const uint64_t m = mrow[wd];
-    if (m == 0) continue;
-    if ((m >> lane) & 1ull) {
-      const int col = wd * 64 + lane;
-      KeyVal kv;
-      key_eval(C, C - lstep, C + lstep, gauss + poff, og.wa, t.row * og.wa + col, dp, &kv);
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < cap_raw) {
-        RawKey rk;
-        rk.level_index = t.li; rk.col = col; rk.row = t.row; rk.packed = kv.packed;
-        rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
-        out[pos] = rk;
+__global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* deth,
+                                                           uint64_t* rowmask, int* rowcnt) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [dog+2][EX_TR+2][EX_STRIDE]
+  __shared__ unsigned short cand[EX_TR * EX_TC];
+  __shared__ unsigned long long mwords[EX_TR][EX_TC / 64];
+  __shared__ int ncand;
+  const int b = blockIdx.y;
+  int o = 0;
+  for (int k = 1; k < g.noct; k++)
+    if (g.o[k].tile_base <= (int)blockIdx.x) o = k;
+  const OctGeom& og = g.o[o];
+  const int trel = blockIdx.x - og.tile_base;
+  const int ty = trel / og.tiles_x, tx = trel - ty * og.tiles_x;
+  const int x0 = tx * EX_TC, y0 = ty * EX_TR;
+  const int nlv = g.dog + 2;
+  constexpr int ROWS = EX_TR + 2, NG = (EX_TC + 8) / 4;
+  // ---- stage 0: global -> LDS (zeros outside the plane; those cells are never used by a valid test).
+  // Eight independent 16-byte loads are issued before the first LDS store so their HBM latencies overlap
+  // (a load->store loop with a run-time trip count serialises one memory round trip per iteration).
+  const int ngroups = nlv * ROWS * NG;
+  for (int g0 = 0; g0 < ngroups; g0 += 8 * 256) {
+    float4 v[8];
+    int dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[u] = -1;
+      if (gi < ngroups) {
+        const int l = gi / (ROWS * NG);
+        const int rem = gi - l * (ROWS * NG);
+        const int r = rem / NG, gx = rem - r * NG;
+        const int y = y0 - 1 + r, x = x0 - 4 + gx * 4;
+        dst[u] = (l * ROWS + r) * EX_STRIDE + gx * 4;
+        const bool ok = (y >= 0 && y < og.h && x >= 0 && x < og.wa);
+        const int yc = ok ? y : 0, xc = ok ? x : 0;  // branch-free: always load, select afterwards
+        const float4 q = *reinterpret_cast<const float4*>(deth + og.lvl_off + ((long long)l * g.B + b) * og.plane + (long long)yc * og.wa + xc);
+        if (ok) v[u] = q;
       }
     }
-    base += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (dst[u] >= 0) *reinterpret_cast<float4*>(&tile[dst[u]]) = v[u];
   }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int l = 1; l <= g.dog; l++) {
+    if (threadIdx.x == 0) ncand = 0;
+    if (threadIdx.x < EX_TR * (EX_TC / 64)) (&mwords[0][0])[threadIdx.x] = 0ull;
+    __syncthreads();  // also orders stage 0 (first level) / the previous level's write-out
+    const float* C = tile + (l * ROWS) * EX_STRIDE;
+    const float* P = C - ROWS * EX_STRIDE;
+    const float* N = C + ROWS * EX_STRIDE;
+    // ---- stage 1: wave w owns tile rows 2w, 2w+1.  Branch-free necessary condition with 27
+    // independent LDS reads: a keypoint's response is beyond the first threshold and is >= all 26
+    // neighbours or <= all of them (the reference's running nmax/nmin chain implies it).  The exact,
+    // order-dependent test runs in stage 2 on the survivors only. ----
+#pragma unroll 1
+    for (int it = 0; it < (EX_TR / 4) * (EX_TC / 64); it++) {
+      const int rl_ = wv * (EX_TR / 4) + (it >> 2), blk = it & 3;
+      const int row = y0 + rl_, col = x0 + blk * 64 + lane;
+      const int ci = (rl_ + 1) * EX_STRIDE + (blk * 64 + lane + 4);
+      const float r = C[ci];
+      float mx = -3.402823466e38f, mn = 3.402823466e38f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          const int k = ci + dy * EX_STRIDE + dx;
+          const float a = P[k], c2 = N[k];
+          mx = fmaxf(mx, fmaxf(a, c2));
+          mn = fminf(mn, fminf(a, c2));
+          if (dy != 0 || dx != 0) {
+            const float q = C[k];
+            mx = fmaxf(mx, q);
+            mn = fminf(mn, q);
+          }
+        }
+      }
+      const bool flag = (row > 0 && row < og.h - 1 && col > 0 && col < og.wa - 1) && (fabsf(r) > dp.thr0) &&
+                        ((r >= mx) || (r <= mn));
+      const uint64_t m = __ballot(flag);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ncand, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (flag) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((rl_ << 8) | (blk * 64 + lane));
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: one candidate per lane ----
+    const int nc = ncand;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+      const int code = cand[i];
+      const int rl_ = code >> 8, cl = code & 255;
+      if (key_eval<false>(C, P, N, nullptr, EX_STRIDE, (rl_ + 1) * EX_STRIDE + (cl + 4), dp, nullptr))
+        atomicOr(&mwords[rl_][cl >> 6], 1ull << (cl & 63));
+    }
+    __syncthreads();
+    // ---- write-out: mask words and row counts of this level ----
+    if (threadIdx.x < EX_TR * (EX_TC / 64)) {
+      const int rl_ = threadIdx.x >> 2, blk = threadIdx.x & 3;
+      const int row = y0 + rl_;
+      if (row < og.h && x0 + blk * 64 < og.wa) {
+        const unsigned long long m = mwords[rl_][blk];
+        rowmask[(long long)b * g.NM + og.mask_base + ((l - 1) * og.h + row) * og.w64 + (x0 >> 6) + blk] = m;
+        if (m) atomicAdd(&rowcnt[(long long)b * g.NR + og.row_base + (l - 1) * og.h + row], __popcll(m));
+      }
+    }
+  }
+}
+
+// Extrema scan pass 2: one thread per detection.  Thread i of image b finds its row by binary search
+// in the exclusive row offsets, its column as the (i - offset)-th set bit of the row's mask words,
+// recomputes the keypoint (all lanes busy) and writes raw[i]: row-major order by construction.
+__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, const float* gauss,
+                                                              const float* deth, const uint64_t* rowmask,
+                                                              const int* rowoff, const int* raw_total,
+                                                              RawKey* raw, int cap_raw) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = raw_total[b];
+  if (i >= n) return;
+  const int* off = rowoff + (long long)b * g.NR;
+  // the detection's row is the LAST row whose exclusive offset is <= i (offsets are non-decreasing;
+  // empty rows and rows of levels dropped by -tc count 0 and so never qualify as the last one)
+  int lo = 0, hi = g.NR - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  const int ri = lo;
+  int oct = 0;
+  for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= ri) oct = k;
+  const OctGeom& og = g.o[oct];
+  const int rel = ri - og.row_base;
+  const int lm1 = rel / og.h, row = rel - lm1 * og.h, l = lm1 + 1;
+  const uint64_t* mrow = rowmask + (long long)b * g.NM + og.mask_base + (lm1 * og.h + row) * og.w64;
+  int rank = i - off[ri];
+  int col = -1;
+  for (int wd = 0; wd < og.w64; wd++) {
+    uint64_t m = mrow[wd];
+    const int c = __popcll(m);
+    if (rank < c) {
+      for (int k = 0; k < rank; k++) m &= m - 1;  // drop the lower `rank` set bits
+      col = wd * 64 + __builtin_ctzll(m);
+      break;
+    }
+    rank -= c;
+  }
+  if (col < 0) return;  // cannot happen: counts and masks come from the same pass
+  const long long poff = og.lvl_off + ((long long)l * g.B + b) * og.plane;
+  const long long lstep = (long long)g.B * og.plane;
+  const float* C = deth + poff;
+  KeyVal kv;
+  key_eval<false>(C, C - lstep, C + lstep, gauss + poff, og.wa, row * og.wa + col, dp, &kv);
+  RawKey rk;
+  rk.level_index = oct * g.dog + lm1; rk.col = col; rk.row = row; rk.packed = kv.packed;
+  rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
+  raw[(long long)b * cap_raw + i] = rk;
 }
 
 // =============================== block scan helpers ==========================================
@@ -381,7 +496,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
     int e, e2, tot, tot2;
     block_scan2(c, 0, &e, &e2, &tot, &tot2, lds);
     const int cbase = carry;
-    if (i < g.NR) off[i] = kp ? cbase + e : -1;
+    if (i < g.NR) off[i] = cbase + e;  // dropped rows count 0: offsets stay monotone
     __syncthreads();
     if (tid == 0) carry = cbase + tot;
     __syncthreads();
@@ -507,9 +622,16 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                          const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
-  const long long waves = (long long)batch * g.NR;
-  hipLaunchKernelGGL(extrema_mark_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, dp, gauss, deth,
-                     rowmask, rowcnt, batch);
+  (void)gauss;
+  hipMemsetAsync(rowcnt, 0, (size_t)batch * g.NR * sizeof(int), st);
+  const size_t lds = (size_t)(g.dog + 2) * (EX_TR + 2) * EX_STRIDE * sizeof(float);
+  static size_t lds_allowed = 0;  // dog >= 4 needs more than the default 64 KB of dynamic LDS
+  if (lds > lds_allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(extrema_mark_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_allowed = lds;
+  }
+  hipLaunchKernelGGL(extrema_mark_kernel, dim3(g.ntiles, batch), dim3(256), lds, st, g, dp, deth, rowmask, rowcnt);
 }
 
 void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt, int* rowoff,
@@ -519,11 +641,10 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
 }
 
 void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                            const float* deth, const uint64_t* rowmask, const int* rowoff, RawKey* raw,
-                            int cap_raw, int batch) {
-  const long long waves = (long long)batch * g.NR;
-  hipLaunchKernelGGL(extrema_scatter_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, dp, gauss,
-                     deth, rowmask, rowoff, raw, cap_raw, batch);
+                            const float* deth, const uint64_t* rowmask, const int* rowoff, const int* raw_total,
+                            RawKey* raw, int cap_raw, int batch) {
+  hipLaunchKernelGGL(extrema_scatter_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, g, dp, gauss, deth,
+                     rowmask, rowoff, raw_total, raw, cap_raw);
 }
 
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,

@@ -355,42 +355,55 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
       // ---- phase 1: 64 samples of every cell's box, hits appended in scan order to the cell's list ----
       int cnt_l = 0;  // lane c < 16: records of cell c in this round
       int cntmax = 0;
-      for (int cell = 0; cell < 16; cell++) {
-        const int tot_c = rli(total_l, cell);
-        if (t0 >= tot_c) continue;
-        const float ptx = rl(ptx_l, cell), pty = rl(pty_l, cell);
-        const float xmin = rl(xmin_l, cell), ymin = rl(ymin_l, cell);
-        const float offx = rl(offx_l, cell), offy = rl(offy_l, cell);
-        const float inv = rl(inv_l, cell);
-        const int nxs = rli(nxs_l, cell);
-        const int t = t0 + lane;
-        bool hit = false;
-        float theta = 0.0f, wt = 0.0f;
-        if (t < tot_c) {
+      for (int cg = 0; cg < 16; cg += 4) {
+        // stage A (4 cells): geometry, window test, and the gradient gathers issued back to back so
+        // that their latencies overlap (one dependent load per cell would serialise 16 L2 round trips)
+        bool in[4];
+        float nxa[4], nya[4], oxa[4], oya[4];
+        float2 cca[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int cell = cg + u;
+          const int tot_c = rli(total_l, cell);
+          const float ptx = rl(ptx_l, cell), pty = rl(pty_l, cell);
+          const float xmin = rl(xmin_l, cell), ymin = rl(ymin_l, cell);
+          const float inv = rl(inv_l, cell);
+          const int nxs = rli(nxs_l, cell);
+          oxa[u] = rl(offx_l, cell);
+          oya[u] = rl(offy_l, cell);
+          const int t = t0 + lane;
           const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
           const int sx = t - sy * nxs;
           const float x = xmin + (float)sx, y = ymin + (float)sy;
           const float dx = x - ptx, dy = y - pty;
-          const float nx = fmaf(crspt, dx, srspt * dy);
-          const float ny = fmaf(crspt, dy, -(srspt * dx));
-          const float nxn = fabsf(nx), nyn = fabsf(ny);
-          if ((nxn < 1.0f) && (nyn < 1.0f)) {
-            const float2 cc = gp[(int)y * width + (int)x];
-            const float dnx = nx + offx, dny = ny + offy;
+          nxa[u] = fmaf(crspt, dx, srspt * dy);
+          nya[u] = fmaf(crspt, dy, -(srspt * dx));
+          in[u] = (t < tot_c) && (fabsf(nxa[u]) < 1.0f) && (fabsf(nya[u]) < 1.0f);
+          cca[u] = gp[in[u] ? (int)y * width + (int)x : 0];
+        }
+        // stage B: weights, ordered append to the cell's list
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int cell = cg + u;
+          bool hit = false;
+          float theta = 0.0f, wt = 0.0f;
+          if (in[u]) {
+            const float nxn = fabsf(nxa[u]), nyn = fabsf(nya[u]);
+            const float dnx = nxa[u] + oxa[u], dny = nya[u] + oya[u];
             const float ww = dm_expf(-0.125f * fmaf(dnx, dnx, dny * dny));
             const float wx = 1.0f - nxn, wy = 1.0f - nyn;
-            wt = ww * wx * wy * cc.x;
-            theta = (anglef - cc.y) * rpi;
+            wt = ww * wx * wy * cca[u].x;
+            theta = (anglef - cca[u].y) * rpi;
             if (theta < 0) theta += 8.0f;
             // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771)
             hit = (theta >= 0.0f) && (theta < 8.0f);
           }
+          const uint64_t mk = __ballot(hit);
+          if (hit) rlist[cell * 64 + __popcll(mk & ((1ull << lane) - 1ull))] = make_float2(theta, wt);
+          const int nrec = __popcll(mk);
+          if (lane == cell) cnt_l = nrec;
+          cntmax = max(cntmax, nrec);
         }
-        const uint64_t mk = __ballot(hit);
-        if (hit) rlist[cell * 64 + __popcll(mk & ((1ull << lane) - 1ull))] = make_float2(theta, wt);
-        const int nrec = __popcll(mk);
-        if (lane == cell) cnt_l = nrec;
-        cntmax = max(cntmax, nrec);
       }
       // ---- phase 2: the four lanes of a cell walk its list in order; one fmaf per record and lane ----
       const int nmine = __shfl(cnt_l, mycell);

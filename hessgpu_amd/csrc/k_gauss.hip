@@ -51,32 +51,48 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   const long long img = blockIdx.z;
 
   // ---- stage 1: global -> LDS, replicate borders (ProgramCU.cu:138, :201) ----
-  for (int g = tid; g < ROWS * NG; g += NT) {
-    int r = g / NG, gx = g - r * NG;
+  // All of a thread's loads are issued before its first LDS store, so their HBM latencies overlap.
+  constexpr int NIT = (ROWS * NG + NT - 1) / NT;
+  // Straight-line, branch-free loads (clamped row, clamped 16-byte-aligned column group) stored raw;
+  // groups that lie left/right of the image are patched afterwards (border tiles only).
+  float4 stage[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int g = it * NT + tid;
+    g = g < ROWS * NG ? g : ROWS * NG - 1;  // surplus threads repeat the last group
+    const int r = g / NG, gx = g - r * NG;
     int y = y0 - R + r;
     y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-    int x = x0 - R4 + gx * 4;
-    float4 v;
+    const int x = x0 - R4 + gx * 4;
+    const int xs = x < 0 ? 0 : (x >= w ? w - 4 : x);  // w is a multiple of 4
     if (U8) {
       const uint8_t* row = a.src_u8 + img * a.src_img_stride + (long long)y * a.src_pitch;
-      if (x >= 0 && x < w) {
-        uchar4 b = *reinterpret_cast<const uchar4*>(row + x);
-        v.x = (float)b.x / 255.0f; v.y = (float)b.y / 255.0f;   // GLTexImage.cpp:828
-        v.z = (float)b.z / 255.0f; v.w = (float)b.w / 255.0f;
-      } else {
-        float e = (float)row[x < 0 ? 0 : w - 1] / 255.0f;
-        v = make_float4(e, e, e, e);
-      }
+      const uchar4 b = *reinterpret_cast<const uchar4*>(row + xs);
+      stage[it] = make_float4((float)b.x / 255.0f, (float)b.y / 255.0f,   // GLTexImage.cpp:828
+                              (float)b.z / 255.0f, (float)b.w / 255.0f);
     } else {
       const float* row = a.src + img * a.src_img_stride + (long long)y * a.src_pitch;
-      if (x >= 0 && x < w) {
-        v = *reinterpret_cast<const float4*>(row + x);
-      } else {
-        float e = row[x < 0 ? 0 : w - 1];
-        v = make_float4(e, e, e, e);
+      stage[it] = *reinterpret_cast<const float4*>(row + xs);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int g = it * NT + tid;
+    g = g < ROWS * NG ? g : ROWS * NG - 1;
+    const int r = g / NG, gx = g - r * NG;
+    *reinterpret_cast<float4*>(&s[r * SWP + gx * 4]) = stage[it];
+  }
+  if (x0 - R4 < 0 || x0 + TW + R4 > w) {  // block-uniform: replicate the edge pixel into outside groups
+    __syncthreads();
+    for (int g = tid; g < ROWS * NG; g += NT) {
+      const int r = g / NG, gx = g - r * NG;
+      const int x = x0 - R4 + gx * 4;
+      if (x < 0 || x >= w) {
+        // the group holds source columns 0..3 (left) or w-4..w-1 (right): take the edge one
+        const float e = s[r * SWP + gx * 4 + (x < 0 ? 0 : 3)];
+        *reinterpret_cast<float4*>(&s[r * SWP + gx * 4]) = make_float4(e, e, e, e);
       }
     }
-    *reinterpret_cast<float4*>(&s[r * SWP + gx * 4]) = v;
   }
   __syncthreads();
 
