@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images per GPU (tiled to --batch)")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) pipelined per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     args = ap.parse_args()
@@ -75,15 +76,34 @@ def main():
     imgs = np.concatenate([imgs] * ((B + nd - 1) // nd))[:B]
     d_imgs = torch.from_numpy(imgs).to(dev)  # [B,H,W] u8 resident in HBM
 
-    ctx = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK)
-    ctx.reserve(W, H, B)
+    # Two contexts used alternately: while one batch's results travel to the host (and, for N > 1,
+    # are gathered over RCCL), the next batch's kernels already run on the other context's stream.
+    nctx = max(1, args.contexts)
+    ctxs = [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK)
+            for _ in range(nctx)]
+    for c in ctxs:
+        c.reserve(W, H, B)
 
-    def step():
-        ctx.run_device(d_imgs.data_ptr(), B, H, W)
-        counts = [ctx.count(b) for b in range(B)]
+    def finish(c):
+        c.wait()
+        counts = [c.count(b) for b in range(B)]
         if use_dist:
-            keys, desc = hdist.device_feature_tensors(ctx, counts, dev)
+            keys, desc = hdist.device_feature_tensors(c, counts, dev)
             hdist.gather_feature_lists(counts, keys, desc, dst=0)
+        return counts
+
+    def run_steps(n):
+        """n steps, software-pipelined over the contexts; every step is submitted and finished inside."""
+        counts = None
+        inflight = []
+        for i in range(n):
+            c = ctxs[i % nctx]
+            if len(inflight) == nctx:
+                counts = finish(inflight.pop(0))
+            c.submit_device(d_imgs.data_ptr(), B, H, W)
+            inflight.append(c)
+        while inflight:
+            counts = finish(inflight.pop(0))
         return counts
 
     def fence():
@@ -91,23 +111,31 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        counts = step()
-    if not args.no_profile:
-        ctx.profile_enable(True)
-        ctx.profile_reset()
+    counts = run_steps(max(args.warmup, 1))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()
+    counts = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
-    prof = ctx.profile() if not args.no_profile else None
-    ctx.profile_enable(False)
+    for c in ctxs:
+        c.profile_enable(False)
+    # Roofline leg: per-kernel hipEvent durations are only meaningful when kernels of different
+    # streams do not overlap, so with more than one pipelined context the events are recorded in a
+    # separate single-stream leg of the same run (same batch, same inputs, one context).
+    prof, roof_steps = None, 0
+    if not args.no_profile:
+        c = ctxs[0]
+        roof_steps = max(3, min(args.steps, 10))
+        c.profile_enable(True)
+        c.profile_reset()
+        for _ in range(roof_steps):
+            c.run_device(d_imgs.data_ptr(), B, H, W)
+        prof = c.profile()
+        c.profile_enable(False)
 
     if rank == 0:
         pixels = float(world) * B * args.steps * W * H
@@ -128,6 +156,7 @@ def main():
             "config": {
                 "workload": "1920x1080 synthetic blobs (tests/fixtures.py), default octaves/DoG levels, top-K=4096",
                 "images_per_gpu_per_step": B,
+                "pipelined_contexts_per_gpu": nctx,
                 "distinct_images_per_gpu": nd,
                 "features_per_image_mean": round(float(np.mean(counts)), 1),
                 "sharding": f"images over {world} rank(s), RCCL gather of feature lists" if use_dist else "single GPU",
@@ -150,11 +179,13 @@ def main():
                     "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"], 1),
                     "launches": g["launches"],
                 }
-            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items() if v["launches"]}
+                out["roofline"]["leg"] = f"{roof_steps} single-stream steps after the timed region (kernels do not overlap)"
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(imgs[:nd])
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if use_dist:
         tdist.barrier()
         tdist.destroy_process_group()

@@ -146,8 +146,10 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
 // NormalizeDescriptor_Kernel, ProgramCU.cu:1650-2054; keypoint unpack PyramidCU.cpp:866-906).
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
                        int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
-                       const int* feat_first, const float* got, HostKeypoint* keys, float* desc,
-                       int cap_feat, int batch);
+                       const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
+                       float* desc, int cap_feat, int batch);
+// Exclusive prefix of the per-image feature totals: img_base[0..batch] (packed output layout).
+void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch);
 
 // Device evaluation of the elementary functions for the parity tests.
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);

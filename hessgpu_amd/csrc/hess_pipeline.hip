@@ -48,6 +48,14 @@ struct EventPair {
 
 }  // namespace
 
+struct PendingRun {
+  const void* dev;
+  int width, height, pitch, batch, format, pixtype;
+  size_t image_stride;
+  double t_load_ms;
+  bool active;
+};
+
 struct hess_ctx {
   int device = 0;
   hipStream_t st = nullptr;
@@ -66,12 +74,13 @@ struct hess_ctx {
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
   DevBuf gauss, deth, got, input_f32, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
-      hist, sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, keys, desc;
+      hist, sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
   // host results
   int batch = 0;
   std::vector<int> counts;
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
+  PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
   const RawKey* d_list = nullptr;  // list fed to the orientation stage in the last run
   const int* d_list_total = nullptr;
   int cap_list = 0;
@@ -301,6 +310,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->sel_total, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->feat_total, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->feat_first, (size_t)B * 4))) return rc;
+  if ((rc = ensure(c, c->img_base, (size_t)(B + 1) * 4))) return rc;
   if ((rc = ensure(c, c->overflow, 16))) return rc;
   if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
   if (c->use_topk) {
@@ -313,7 +323,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->fsrc, (size_t)B * cap_feat * 4))) return rc;
   if ((rc = ensure(c, c->keys, (size_t)B * cap_feat * sizeof(HostKeypoint)))) return rc;
   if (c->dim && (rc = ensure(c, c->desc, (size_t)B * cap_feat * c->dim * 4))) return rc;
-  if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 4) * 4, true))) return rc;
+  if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 8) * 4, true))) return rc;
 
   c->g = g;
   c->ds = ds;
@@ -481,6 +491,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
                       (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p + 1, batch);
+  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, batch);
   (void)hipEventRecord(c->ev[6], st);
   // ---- descriptors (GetFeatureDescriptors) ----
   DescParams dsp;
@@ -494,62 +505,66 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   {
     ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
     launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
-                      (const int*)c->feat_total.p, (const int*)c->feat_first.p, got,
+                      (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                       (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, batch);
   }
   (void)hipEventRecord(c->ev[7], st);
   return 0;
 }
 
-int run_device_impl(hess_ctx* c, const void* dev, int width, int height, int pitch, size_t image_stride, int batch,
-                    int format, int pixtype, double* t_load_ms) {
-  int rc = plan(c, width, height, batch);
+// Enqueue the whole path and the copy of the per-image counts; returns without waiting.
+int submit_impl(hess_ctx* c, const PendingRun& r) {
+  int rc = plan(c, r.width, r.height, r.batch);
   if (rc) return rc;
   int* hs = (int*)c->h_small.p;
-  for (int attempt = 0; attempt < 8; attempt++) {
-    HIP_TRY(c, hipGetLastError());
-    rc = enqueue(c, dev, pitch, image_stride, batch, format, pixtype);
-    if (rc) return rc;
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(hs, c->feat_total.p, (size_t)batch * 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipMemcpyAsync(hs + batch, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(c, hipGetLastError());
+  rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
+  if (rc) return rc;
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(hs, c->img_base.p, (size_t)(r.batch + 1) * 4, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(c, hipMemcpyAsync(hs + r.batch + 1, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+  return 0;
+}
+
+// Wait for the submitted batch, grow storage and re-run if a list overflowed, then bring the
+// keypoints and descriptors of the whole batch to the host with one transfer each.
+int wait_impl(hess_ctx* c, const PendingRun& r) {
+  int rc;
+  int* hs = (int*)c->h_small.p;
+  const int batch = r.batch;
+  for (int attempt = 0;; attempt++) {
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    const int of_raw = hs[batch], of_feat = hs[batch + 1];
+    const int of_raw = hs[batch + 1], of_feat = hs[batch + 2];
     if (!of_raw && !of_feat) break;
+    if (attempt >= 8) { set_err(c, "feature storage keeps overflowing"); return HESS_ERR_NOMEM; }
     // grow-only reallocation, then run the batch again (reference: SetLevelFeatureNum grows on demand)
     if (of_raw) c->cap_raw = of_raw + of_raw / 4;
     if (of_feat) c->cap_feat = of_feat + of_feat / 4;
     c->planned = false;
     if (c->p.verbose) fprintf(stderr, "hessgpu: feature storage grown (raw %d, features %d)\n", c->cap_raw, c->cap_feat);
-    rc = plan(c, width, height, batch);
-    if (rc) return rc;
+    if ((rc = submit_impl(c, r))) return rc;
   }
   drain_profile(c);
-  // ---- results to host: one transfer of keypoints, one of descriptors per image ----
   c->batch = batch;
-  c->counts.assign(hs, hs + batch);
+  c->counts.resize(batch);
   c->offs.assign(batch + 1, 0);
-  for (int b = 0; b < batch; b++) c->offs[b + 1] = c->offs[b] + (size_t)c->counts[b];
+  for (int b = 0; b < batch; b++) {
+    c->counts[b] = hs[b + 1] - hs[b];
+    c->offs[b + 1] = (size_t)hs[b + 1];
+  }
   const size_t total = c->offs[batch];
   if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
   if (c->dim && (rc = ensure(c, c->h_desc, (total ? total : 1) * c->dim * 4, true))) return rc;
-  for (int b = 0; b < batch; b++) {
-    const size_t n = (size_t)c->counts[b];
-    if (!n) continue;
-    HIP_TRY(c, hipMemcpyAsync((HostKeypoint*)c->h_keys.p + c->offs[b], (HostKeypoint*)c->keys.p + (size_t)b * c->cap_feat,
-                              n * sizeof(HostKeypoint), hipMemcpyDeviceToHost, c->st));
+  if (total) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_keys.p, c->keys.p, total * sizeof(HostKeypoint), hipMemcpyDeviceToHost, c->st));
     if (c->dim)
-      HIP_TRY(c, hipMemcpyAsync((float*)c->h_desc.p + c->offs[b] * c->dim,
-                                (float*)c->desc.p + (size_t)b * c->cap_feat * c->dim, n * c->dim * 4,
-                                hipMemcpyDeviceToHost, c->st));
+      HIP_TRY(c, hipMemcpyAsync(c->h_desc.p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
   }
-  hipEvent_t evd = c->ev[0];  // reuse: record end of download
-  (void)evd;
-  HIP_TRY(c, hipStreamSynchronize(c->st));
   // stage times from the events of the last enqueue (config.h:17-31 order)
   memset(c->timing, 0, sizeof(c->timing));
   auto el = [&](int i, int j) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; };
-  c->timing[HESS_T_LOAD] = t_load_ms ? (float)*t_load_ms : 0.0f;
+  c->timing[HESS_T_LOAD] = (float)r.t_load_ms;
   c->timing[HESS_T_PYRAMID] = el(0, 1);
   c->timing[HESS_T_DETECT] = el(1, 2);
   c->timing[HESS_T_LIST] = el(2, 3);
@@ -606,7 +621,7 @@ void hess_destroy(hess_ctx* c) {
   if (c->st) (void)hipStreamSynchronize(c->st);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->overflow, &c->raw, &c->sel, &c->hist, &c->sel_total,
-                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first,
+                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
   for (DevBuf* b : bufs) release(*b);
   release(c->h_keys, true);
@@ -616,6 +631,7 @@ void hess_destroy(hess_ctx* c) {
   for (auto& ep : c->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->st) (void)hipStreamDestroy(c->st);
+  delete c->pend;
   delete c;
 }
 
@@ -625,29 +641,54 @@ int hess_reserve(hess_ctx* c, int width, int height, int batch) {
   return plan(c, width, height, batch);
 }
 
-int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
-                    int batch, int format, int pixtype) {
-  if (!c) return HESS_ERR_ARG;
-  if (!dev_pixels || width <= 0 || height <= 0 || batch <= 0 || pitch <= 0 || !fmt_channels(format) ||
-      pixtype < HESS_PIX_U8 || pixtype > HESS_PIX_F32) {
-    set_err(c, "bad argument");
-    return HESS_ERR_ARG;
-  }
-  HIP_TRY(c, hipSetDevice(c->device));
-  return run_device_impl(c, dev_pixels, width, height, pitch, image_stride, batch, format, pixtype, nullptr);
-}
-
-int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
-                  int format, int pixtype) {
+static int check_run_args(hess_ctx* c, const void* pixels, int width, int height, int pitch, int batch, int format,
+                          int pixtype) {
   if (!c) return HESS_ERR_ARG;
   if (!pixels || width <= 0 || height <= 0 || batch <= 0 || pitch <= 0 || !fmt_channels(format) ||
       pixtype < HESS_PIX_U8 || pixtype > HESS_PIX_F32) {
     set_err(c, "bad argument");
     return HESS_ERR_ARG;
   }
+  return 0;
+}
+
+int hess_submit_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
+                       int batch, int format, int pixtype) {
+  int rc = check_run_args(c, dev_pixels, width, height, pitch, batch, format, pixtype);
+  if (rc) return rc;
+  if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->pend) c->pend = new PendingRun();
+  *c->pend = PendingRun{dev_pixels, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false};
+  rc = submit_impl(c, *c->pend);
+  if (rc) return rc;
+  c->pend->active = true;
+  return 0;
+}
+
+int hess_wait(hess_ctx* c) {
+  if (!c) return HESS_ERR_ARG;
+  if (!c->pend || !c->pend->active) { set_err(c, "nothing submitted"); return HESS_ERR_STATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->pend->active = false;
+  return wait_impl(c, *c->pend);
+}
+
+int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
+                    int batch, int format, int pixtype) {
+  int rc = hess_submit_device(c, dev_pixels, width, height, pitch, image_stride, batch, format, pixtype);
+  if (rc) return rc;
+  return hess_wait(c);
+}
+
+int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
+                  int format, int pixtype) {
+  int rc = check_run_args(c, pixels, width, height, pitch, batch, format, pixtype);
+  if (rc) return rc;
+  if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = (size_t)(batch - 1) * image_stride + (size_t)height * pitch;
-  int rc = ensure(c, c->stage, bytes + 16);
+  rc = ensure(c, c->stage, bytes + 16);
   if (rc) return rc;
   hipEvent_t a = c->ev[0], b = c->ev[1];
   (void)hipEventRecord(a, c->st);
@@ -656,8 +697,11 @@ int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pi
   HIP_TRY(c, hipStreamSynchronize(c->st));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, a, b);
-  double load = ms;
-  return run_device_impl(c, c->stage.p, width, height, pitch, image_stride, batch, format, pixtype, &load);
+  if (!c->pend) c->pend = new PendingRun();
+  *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, (double)ms, false};
+  rc = submit_impl(c, *c->pend);
+  if (rc) return rc;
+  return wait_impl(c, *c->pend);
 }
 
 int hess_count(hess_ctx* c, int img) {
@@ -679,7 +723,7 @@ int hess_device_results(hess_ctx* c, const void** keys, const void** desc, int* 
   if (!c || !c->batch) return HESS_ERR_STATE;
   if (keys) *keys = c->keys.p;
   if (desc) *desc = c->dim ? c->desc.p : nullptr;
-  if (capacity) *capacity = c->cap_feat;
+  if (capacity) *capacity = (int)c->offs[c->batch];  // records in use; image b starts at sum of counts < b
   return 0;
 }
 

@@ -275,13 +275,15 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
                                                          int cap_list, const FRec* recs,
                                                          const int* fsrc, const int* feat_total,
-                                                         const int* feat_first, const float* got,
-                                                         HostKeypoint* keys, float* desc, int cap_feat) {
+                                                         const int* feat_first, const int* img_base,
+                                                         const float* got, HostKeypoint* keys, float* desc,
+                                                         int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
   __shared__ float2 rec_lds[4][16][64];  // per wavefront: one round's (theta, weight) records per cell
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int ftotal = feat_total[b], ffirst = feat_first[b];
+  const long long obase = img_base[b];  // packed output: images of the batch back to back
   const int nwaves = gridDim.x * 4;
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
       hk.response = dm_h2f(((rec.x & 0xFF000000u) >> 16) | ((rec.y & 0xFF000000u) >> 24));
       hk.level = (uint16_t)li;
       hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
-      keys[(long long)b * cap_feat + oidx] = hk;
+      keys[obase + oidx] = hk;
     }
     if (!desc) continue;
 
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
       dl[wv][mycell * 8 + 4 + sub] = acc_hi;
     }
     // same wavefront wrote dl[wv]; LDS operations of one wavefront complete in order
-    float* dout = desc + ((long long)b * cap_feat + oidx) * dim;
+    float* dout = desc + (obase + oidx) * dim;
     if (dp.half_sift) {
       float2 v = make_float2(0, 0);
       if (lane < 32) v = *reinterpret_cast<const float2*>(&dl[wv][lane * 2]);
@@ -479,7 +481,19 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   }
 }
 
+__global__ void image_base_kernel(const int* feat_total, int* img_base, int batch) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < batch; b++) { img_base[b] = acc; acc += feat_total[b]; }
+    img_base[batch] = acc;
+  }
+}
+
 }  // namespace
+
+void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch) {
+  hipLaunchKernelGGL(image_base_kernel, dim3(1), dim3(64), 0, st, feat_total, img_base, batch);
+}
 
 void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,
                         const int* list_total, int cap_list, const float* got, FRec* recs, int* ocount,
@@ -500,13 +514,13 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
 
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
                        int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
-                       const int* feat_first, const float* got, HostKeypoint* keys, float* desc, int cap_feat,
-                       int batch) {
+                       const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
+                       float* desc, int cap_feat, int batch) {
   int blocks = (cap_feat + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), 0, st, g, dp, list, cap_list, recs, fsrc,
-                     feat_total, feat_first, got, keys, desc, cap_feat);
+                     feat_total, feat_first, img_base, got, keys, desc, cap_feat);
 }
 
 }  // namespace hess

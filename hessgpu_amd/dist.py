@@ -71,17 +71,16 @@ class _DevArray:
 
 
 def device_feature_tensors(ctx, counts, device):
-    """Pack the device-resident results of the last run (hess_device_results) of every local image
-    back to back: -> (keys uint8 [total,24], desc float32 [total,dim] or None), on `device`."""
-    kptr, dptr, cap = ctx.device_results()
+    """Zero-copy views of the device-resident, already packed results of the last run
+    (hess_device_results): -> (keys uint8 [total,24], desc float32 [total,dim] or None)."""
+    kptr, dptr, total = ctx.device_results()
+    assert total == sum(counts)
     dim = ctx.desc_dim()
-    nb = len(counts)
-    kall = torch.as_tensor(_DevArray(kptr, (nb, cap, KEY_BYTES), "|u1"), device=device)
-    keys = torch.cat([kall[b, : counts[b]] for b in range(nb)]) if nb else kall.reshape(0, KEY_BYTES)
-    desc = None
-    if dim and dptr:
-        dall = torch.as_tensor(_DevArray(dptr, (nb, cap, dim), "<f4"), device=device)
-        desc = torch.cat([dall[b, : counts[b]] for b in range(nb)])
+    if total == 0:
+        return (torch.zeros((0, KEY_BYTES), dtype=torch.uint8, device=device),
+                torch.zeros((0, dim), dtype=torch.float32, device=device) if dim else None)
+    keys = torch.as_tensor(_DevArray(kptr, (total, KEY_BYTES), "|u1"), device=device)
+    desc = torch.as_tensor(_DevArray(dptr, (total, dim), "<f4"), device=device) if (dim and dptr) else None
     return keys, desc
 
 

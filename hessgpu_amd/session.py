@@ -96,6 +96,19 @@ class Session:
                                           pitch * height, batch, fmt, pixtype))
         self._batch = batch
 
+    def submit_device(self, dev_ptr, batch, height, width, channels=1, pixtype=_abi.PIX_U8, fmt=None):
+        """Asynchronous half of run_device: enqueue on the context's stream and return."""
+        fmt = fmt or _FMT_BY_CHANNELS[channels]
+        isz = {_abi.PIX_U8: 1, _abi.PIX_U16: 2, _abi.PIX_F32: 4}[pixtype]
+        pitch = width * channels * isz
+        self._check(self._f["submit_device"](self._h, C.c_void_p(dev_ptr), width, height, pitch,
+                                             pitch * height, batch, fmt, pixtype))
+        self._batch = batch
+
+    def wait(self):
+        """Block until the submitted batch's keypoints and descriptors are in host memory."""
+        self._check(self._f["wait"](self._h))
+
     def reserve(self, width, height, batch):
         self._check(self._f["reserve"](self._h, width, height, batch))
 
@@ -141,7 +154,7 @@ class Session:
         return np.array([p[i] for i in range(_abi.T_COUNT)], dtype=np.float32)
 
     def device_results(self):
-        """-> (keys_ptr, desc_ptr, capacity): device buffers of the last run (product only)."""
+        """-> (keys_ptr, desc_ptr, total): packed device results of the last run (product only)."""
         k, d, cap = C.c_void_p(), C.c_void_p(), C.c_int()
         self._check(self._f["device_results"](self._h, C.byref(k), C.byref(d), C.byref(cap)))
         return k.value, d.value, cap.value

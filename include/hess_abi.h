@@ -133,6 +133,12 @@ int hess_reserve(hess_ctx* ctx, int width, int height, int batch);
  * rows `pitch` bytes apart).  Host pointer version: pixels are copied to the device. */
 int hess_run_host(hess_ctx* ctx, const void* pixels, int width, int height, int pitch,
                   size_t image_stride, int batch, int format, int pixtype);
+/* Asynchronous pair: hess_submit_device enqueues the whole path on the context's stream and returns;
+ * hess_wait blocks until the results are in host memory.  Two contexts used alternately overlap the
+ * result transfer of one batch with the kernels of the next.  One submitted batch per context. */
+int hess_submit_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
+                       size_t image_stride, int batch, int format, int pixtype);
+int hess_wait(hess_ctx* ctx);
 /* Same, pixels already resident in device memory (HBM) of ctx's device. */
 int hess_run_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
                     size_t image_stride, int batch, int format, int pixtype);
@@ -146,9 +152,10 @@ int hess_desc_dim(hess_ctx* ctx);
 int hess_fetch(hess_ctx* ctx, int img, hess_keypoint* keys, float* desc);
 
 /* Device-resident results of the last run, for consumers that stay on the GPU (the multi-GPU
- * gather over RCCL): keys = [batch][capacity] hess_keypoint, desc = [batch][capacity][dim] float,
- * image b holds hess_count(b) valid records.  Pointers stay valid until the next run. */
-int hess_device_results(hess_ctx* ctx, const void** keys, const void** desc, int* capacity);
+ * gather over RCCL): keys = [total] hess_keypoint, desc = [total][dim] float, the images of the
+ * batch back to back (image b starts at hess_count(0)+..+hess_count(b-1)); *total = records in use.
+ * Pointers stay valid until the next run. */
+int hess_device_results(hess_ctx* ctx, const void** keys, const void** desc, int* total);
 
 /* Pyramid geometry of the last run (PyramidCU.cpp:238-245,274-309): number of octaves, and per
  * octave the aligned width / height. Arrays must hold >= 32 entries. Returns octave count. */

@@ -1,0 +1,65 @@
+"""GPU: the asynchronous submit/wait pair with two contexts, the packed device-resident results,
+and the RCCL gather path (backend "nccl", world size 1 on the one-GPU box)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import fixtures
+
+pytestmark = pytest.mark.gpu
+
+
+def _imgs(n):
+    return np.stack([fixtures.synthetic_blobs(320, 240, i) for i in range(n)])
+
+
+def test_submit_wait_two_contexts_match_synchronous_run(gpu_ctx_factory):
+    import torch
+
+    a, b, ref = gpu_ctx_factory(), gpu_ctx_factory(), gpu_ctx_factory()
+    i1, i2 = _imgs(3), _imgs(6)[3:]
+    d1, d2 = torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()
+    a.submit_device(d1.data_ptr(), 3, 240, 320)
+    b.submit_device(d2.data_ptr(), 3, 240, 320)
+    from hessgpu_amd.session import HessError
+    with pytest.raises(HessError):  # one batch in flight per context
+        a.submit_device(d1.data_ptr(), 3, 240, 320)
+    a.wait()
+    b.wait()
+    for ctx, imgs in ((a, i1), (b, i2)):
+        n = ref.run(imgs)
+        assert [ctx.count(k) for k in range(3)] == n and sum(n) > 0
+        for k in range(3):
+            kk, dd = ctx.fetch(k)
+            rk, rd = ref.fetch(k)
+            assert kk.tobytes() == rk.tobytes() and dd.tobytes() == rd.tobytes()
+    with pytest.raises(HessError):
+        a.wait()  # nothing submitted
+
+
+def test_device_results_are_packed_and_gather_over_nccl(gpu_ctx_factory):
+    import torch
+    import torch.distributed as dist
+
+    from hessgpu_amd import dist as hdist
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = gpu_ctx_factory(truncate_method=3, feature_count_threshold=200)
+        imgs = _imgs(4)
+        counts = g.run(imgs)
+        keys, desc = hdist.device_feature_tensors(g, counts, dev)
+        assert keys.shape == (sum(counts), 24) and desc.shape == (sum(counts), 128)
+        allc, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0)
+        assert allc == [counts]
+        hk = np.concatenate([np.frombuffer(g.fetch(b)[0].tobytes(), np.uint8).reshape(-1, 24) for b in range(4)])
+        hd = np.concatenate([g.fetch(b)[1] for b in range(4)])
+        assert np.array_equal(gk[0].cpu().numpy(), hk)
+        assert np.array_equal(gd[0].cpu().numpy().view(np.uint32), hd.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
