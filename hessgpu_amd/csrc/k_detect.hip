@@ -49,24 +49,35 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
   const int n = a.plane;
   const int idx = row * a.wa + x;
 
+  // Rows idx-wa, idx, idx+wa as 16-byte loads.  The +-1 neighbours are, in the reference's 1-D
+  // addressing, simply the adjacent thread's outer elements (also across a row end), so they come
+  // from the neighbouring lanes; only the first/last lane of a wavefront (or of the grid) loads them.
   float U[6], M[6], D[6];
   {
-    float4 m = *reinterpret_cast<const float4*>(src + idx);
+    const float4 m = *reinterpret_cast<const float4*>(src + idx);
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int iu = row >= 1 ? idx - a.wa : idx, id = row + 1 < a.h ? idx + a.wa : idx;
+    const float4 uq = *reinterpret_cast<const float4*>(src + iu);
+    const float4 dq = *reinterpret_cast<const float4*>(src + id);
+    if (row >= 1) u = uq;
+    if (row + 1 < a.h) d = dq;
     M[1] = m.x; M[2] = m.y; M[3] = m.z; M[4] = m.w;
-    M[0] = tex1(src, n, idx - 1);
-    M[5] = tex1(src, n, idx + 4);
-    if (row >= 1) {
-      float4 u = *reinterpret_cast<const float4*>(src + idx - a.wa);
-      U[1] = u.x; U[2] = u.y; U[3] = u.z; U[4] = u.w;
-    } else { U[1] = U[2] = U[3] = U[4] = 0.0f; }
-    U[0] = tex1(src, n, idx - a.wa - 1);
-    U[5] = tex1(src, n, idx - a.wa + 4);
-    if (row + 1 < a.h) {
-      float4 d = *reinterpret_cast<const float4*>(src + idx + a.wa);
-      D[1] = d.x; D[2] = d.y; D[3] = d.z; D[4] = d.w;
-    } else { D[1] = D[2] = D[3] = D[4] = 0.0f; }
-    D[0] = tex1(src, n, idx + a.wa - 1);
-    D[5] = tex1(src, n, idx + a.wa + 4);
+    U[1] = u.x; U[2] = u.y; U[3] = u.z; U[4] = u.w;
+    D[1] = d.x; D[2] = d.y; D[3] = d.z; D[4] = d.w;
+  }
+  {
+    const int lane = threadIdx.x & 63;
+    const int nthreads = groups_per_row * a.h;
+    const float ul = __shfl_up(U[4], 1), ml = __shfl_up(M[4], 1), dl = __shfl_up(D[4], 1);
+    const float ur = __shfl_down(U[1], 1), mr = __shfl_down(M[1], 1), dr = __shfl_down(D[1], 1);
+    U[0] = ul; M[0] = ml; D[0] = dl;
+    U[5] = ur; M[5] = mr; D[5] = dr;
+    if (lane == 0) {
+      U[0] = tex1(src, n, idx - a.wa - 1); M[0] = tex1(src, n, idx - 1); D[0] = tex1(src, n, idx + a.wa - 1);
+    }
+    if (lane == 63 || gid == nthreads - 1) {
+      U[5] = tex1(src, n, idx - a.wa + 4); M[5] = tex1(src, n, idx + 4); D[5] = tex1(src, n, idx + a.wa + 4);
+    }
   }
   const float norm = a.norm[l];
   const bool want_got = (l >= 1 && l <= a.dog);
