@@ -27,6 +27,7 @@ struct GaussArgs {
   long long src_img_stride;  // same unit, between images
   float* dst;                // [batch][h][w]
   int w, h;
+  int tiles_x, tiles_y, batch;
   Taps taps;
 };
 
@@ -46,9 +47,19 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   __shared__ __attribute__((aligned(16))) float t[ROWS * TWP];
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int w = a.w, h = a.h;
-  const long long img = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+  // XCD k takes the k-th contiguous eighth of the tile sequence (x fastest, then y, then image) and
+  // neighbouring tiles -- which share halo rows/columns -- are served by the same 4 MiB L2.
+  const int ntile = a.tiles_x * a.tiles_y * a.batch;
+  const int per_xcd = (ntile + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntile) return;
+  const int tz = tile / (a.tiles_x * a.tiles_y);
+  const int trem = tile - tz * (a.tiles_x * a.tiles_y);
+  const int tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
+  const int x0 = txi * TW, y0 = tyi * TH;
+  const long long img = tz;
 
   // ---- stage 1: global -> LDS, replicate borders (ProgramCU.cu:138, :201) ----
   // All of a thread's loads are issued before its first LDS store, so their HBM latencies overlap.
@@ -151,8 +162,12 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
 }
 
 template <int R>
-void launch_r(hipStream_t st, const GaussArgs& a, int batch) {
-  dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH, batch);
+void launch_r(hipStream_t st, GaussArgs a, int batch) {
+  a.tiles_x = (a.w + TW - 1) / TW;
+  a.tiles_y = (a.h + TH - 1) / TH;
+  a.batch = batch;
+  const int ntile = a.tiles_x * a.tiles_y * batch;
+  dim3 grid(((ntile + 7) / 8) * 8);
   if (a.src_u8)
     hipLaunchKernelGGL((gauss_kernel<R, true>), grid, dim3(NT), 0, st, a);
   else

@@ -143,6 +143,30 @@ def test_parity_1080p_topk(gpu_ctx_factory):
     assert len(o.rawlist(0)) == 4096 and n[0] >= 4096
 
 
+def test_parity_4096_half_topk65536(gpu_ctx_factory):
+    """BASELINE.json configs[4]: 4096x4096 single image, top-K=65536, <0,PI> unsigned-gradient (half)
+    descriptor mode; needs -maxd 4096 (tex_max_dim) exactly as the reference would."""
+    im = fixtures.synthetic_blobs(4096, 4096, 5)
+    kw = dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=65536, half_sift=1, tex_max_dim=4096)
+    g = gpu_ctx_factory(**kw)
+    o = OracleSession(threads=16, keep_levels=False, **kw)
+    n = _compare_all(g, o, im[None], "4096x4096 half top-K 65536", stages=False)
+    assert len(o.geometry()) == 9 and len(o.rawlist(0)) == 65536 and n[0] >= 65536
+    k, d = g.fetch(0)
+    assert d.shape[1] == 64
+    # size-independent properties at full size: unit-norm descriptors, clamp, list order, top-K cut
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5) and d.min() >= 0.0
+    raw = g.rawlist(0)
+    order = np.lexsort((raw["col"], raw["row"], raw["level_index"]))
+    assert np.array_equal(order, np.arange(len(raw)))          # (level,row,col) ascending
+    resp = np.abs((raw["packed"] >> 16).astype(np.uint16).view(np.float16).astype(np.float32))
+    g2 = gpu_ctx_factory(tex_max_dim=4096, compute_descriptors=0, max_orientation=1)
+    g2.run(im[None])
+    allraw = g2.rawlist(0)
+    allresp = np.sort(np.abs((allraw["packed"] >> 16).astype(np.uint16).view(np.float16).astype(np.float32)))[::-1]
+    assert len(allraw) > 65536 and resp.min() >= allresp[65535]  # nothing kept is weaker than the K-th
+
+
 @pytest.mark.parametrize("kw", [
     dict(half_sift=1),
     dict(max_orientation=1),
