@@ -97,8 +97,12 @@ struct DescParams {
 // Separable Gaussian, one level for the whole batch: dst = G(taps) * src with replicated
 // borders, tap order and FMA chain of FilterH/FilterV (ProgramCU.cu:117-231).
 // src_u8 != nullptr: source is u8 luminance (value/255.0f, GLTexImage.cpp:828), pitch in bytes.
+// deth_src != nullptr (float source with src_pitch == wa, src_img_stride == wa*h only): the kernel
+// also emits det-Hessian*sigma^4 (and, if got_src != nullptr, gradient/theta) of the SOURCE level
+// from the window it has staged anyway (ComputeHessian_Kernel, ProgramCU.cu:523-595).
 void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
-                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps);
+                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
+                  float* deth_src = nullptr, float* got_src = nullptr, float norm_src = 0.0f);
 
 // Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
@@ -110,8 +114,11 @@ void launch_downsample(hipStream_t st, const float* src, int sw, int splane, flo
 
 // det-Hessian * sigma^4 for levels 0..dog+1 of one octave, and (gradient, theta) for levels
 // 1..dog (ComputeHessian_Kernel, ProgramCU.cu:523-595).
+// Levels [level_first, level_last] only (the fused Gaussian kernel covers every level that is the
+// source of a blur; the top level of an octave has no successor and is done here).
 void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gauss, float* deth,
-                    float* got, const float* norms /* device: sigma^4 per level */, int batch);
+                    float* got, const float* norms /* host: sigma^4 per level */, int batch,
+                    int level_first, int level_last);
 
 // Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

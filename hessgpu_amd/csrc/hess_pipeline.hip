@@ -419,16 +419,20 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                         plane_ptr(gauss, o, 0), og.wa, og.h, batch);
     }
     for (int l = 1; l <= s.level_max; l++) {
-      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * 8.0);
+      // level l from level l-1; the same launch emits det-H (+ gradient/theta) of level l-1 from the
+      // source window it stages: 8 B R+W for the blur, 4 B (+8 B) W for the fused planes
+      const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
+      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)));
       launch_gauss(st, plane_ptr(gauss, o, l - 1), nullptr, og.wa, og.plane, plane_ptr(gauss, o, l), og.wa, og.h,
-                   batch, s.taps[l]);
+                   batch, s.taps[l], plane_ptr(deth, o, l - 1),
+                   src_got ? got + 2 * (og.got_off + (long long)(l - 2) * g.B * og.plane) : nullptr, s.norm[l - 1]);
     }
   }
   (void)hipEventRecord(c->ev[1], st);
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
-  for (int o = 0; o < g.noct; o++) {
-    ProfScope ps(c, HESS_K_HESSIAN, (double)batch * g.o[o].plane * (8.0 * s.level_num + 8.0 * g.dog));
-    launch_hessian(st, g, o, gauss, deth, got, s.norm, batch);
+  for (int o = 0; o < g.noct; o++) {  // the octave's top level has no successor blur: standalone kernel
+    ProfScope ps(c, HESS_K_HESSIAN, (double)batch * g.o[o].plane * 8.0);
+    launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
   }
   // ---- extrema + ordered list (DetectKeypointsEX part 2 + GenerateFeatureList) ----
   DetectParams dp;

@@ -27,7 +27,7 @@ struct HessArgs {
   const float* gauss;
   float* deth;
   float2* got;
-  int wa, h, plane, B, dog, nlevel, batch;
+  int wa, h, plane, B, dog, level_first, batch;
   long long lvl_off, got_off;
   float norm[kMaxLev];  // sigma_l^4 (host passes sigma^2, wrapper squares it: ProgramCU.cu:592)
 };
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
   const int row = gid / groups_per_row;
   const int x = (gid - row * groups_per_row) << 2;
   const int z = blockIdx.y;  // l * batch + b
-  const int l = z / a.batch, b = z - l * a.batch;
+  const int l = a.level_first + z / a.batch, b = z % a.batch;
   const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
   const float* src = a.gauss + poff;
   const int n = a.plane;
@@ -620,15 +620,16 @@ __global__ void math_probe_kernel(int which, const float* a, const float* b, flo
 }  // namespace
 
 void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gauss, float* deth, float* got,
-                    const float* norms, int batch) {
+                    const float* norms, int batch, int level_first, int level_last) {
   const OctGeom& og = g.o[octave];
   HessArgs a;
   a.gauss = gauss; a.deth = deth; a.got = reinterpret_cast<float2*>(got);
-  a.wa = og.wa; a.h = og.h; a.plane = og.plane; a.B = g.B; a.dog = g.dog; a.nlevel = g.dog + 2;
+  a.wa = og.wa; a.h = og.h; a.plane = og.plane; a.B = g.B; a.dog = g.dog; a.level_first = level_first;
   a.batch = batch; a.lvl_off = og.lvl_off; a.got_off = og.got_off;
   for (int l = 0; l < g.dog + 2; l++) a.norm[l] = norms[l];
   const int groups = (og.wa >> 2) * og.h;
-  hipLaunchKernelGGL(hessian_kernel, dim3((groups + 255) / 256, (g.dog + 2) * batch), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(hessian_kernel, dim3((groups + 255) / 256, (level_last - level_first + 1) * batch), dim3(256),
+                     0, st, a);
 }
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

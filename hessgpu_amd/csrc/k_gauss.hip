@@ -13,6 +13,7 @@
 //            coalesced stores, 512 contiguous bytes per wavefront).
 // Per output the taps are accumulated in the reference's order: v = 0; v = fma(x_i, k_i, v), i=0..FW-1.
 #include "hess_dev.h"
+#include "hess_devmath.h"
 
 namespace hess {
 
@@ -28,10 +29,16 @@ struct GaussArgs {
   float* dst;                // [batch][h][w]
   int w, h;
   int tiles_x, tiles_y, batch;
+  // fused det-Hessian / gradient of the SOURCE level (HESS variant): [batch][h][w] planes
+  float* deth_src;
+  float2* got_src;   // may be null (levels 0 and dog+1 have no gradient plane)
+  float norm_src;    // sigma^4 of the source level
   Taps taps;
 };
 
-template <int R, bool U8>
+__device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
+
+template <int R, bool U8, bool HESS>
 __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   constexpr int FW = 2 * R + 1;
   constexpr int R4 = (R + 3) & ~3;
@@ -107,6 +114,82 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   }
   __syncthreads();
 
+  // ---- stage 1b (HESS): det-Hessian*sigma^4 and (gradient, theta) of the SOURCE level for this tile,
+  // straight from the staged source window: the level is never re-read from HBM for it
+  // (ComputeHessian_Kernel, ProgramCU.cu:523-595).  A thread does 8 pixels of one row. ----
+  if (HESS) {
+    const int hr = tid >> 3, hx = (tid & 7) * 8;
+    const int gy = y0 + hr, gx = x0 + hx;
+    if (gy < h && gx < w) {
+      float U[10], M[10], D[10];  // columns gx-1 .. gx+8 of rows gy-1, gy, gy+1
+      {
+        const float* base = &s[(hr + R - 1) * SWP + hx + R4 - 4];
+        float tmp[3][16];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(base + rr * SWP + 4 * q);
+            tmp[rr][4 * q] = v.x; tmp[rr][4 * q + 1] = v.y; tmp[rr][4 * q + 2] = v.z; tmp[rr][4 * q + 3] = v.w;
+          }
+#pragma unroll
+        for (int j = 0; j < 10; j++) { U[j] = tmp[0][3 + j]; M[j] = tmp[1][3 + j]; D[j] = tmp[2][3 + j]; }
+      }
+      // The staged window replicates the image border; the reference addresses neighbours by 1-D
+      // index instead: rows outside the plane read 0, column -1 / w wraps to the adjacent row.
+      const float* plane = a.src + img * a.src_img_stride;
+      const int n = w * h, idx = gy * w + gx;
+      if (gy == 0) {
+#pragma unroll
+        for (int j = 0; j < 10; j++) U[j] = 0.0f;
+      }
+      if (gy == h - 1) {
+#pragma unroll
+        for (int j = 0; j < 10; j++) D[j] = 0.0f;
+      }
+      if (gx == 0) {
+        U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
+      }
+      const int nvalid = (w - gx) >= 8 ? 8 : 4;  // w is a multiple of 4
+      if (gx + nvalid == w) {                    // this thread owns the row's last pixel
+        const int il = idx + nvalid - 1;
+        const float ur = gtex1(plane, n, il - w + 1), mr = gtex1(plane, n, il + 1), dr = gtex1(plane, n, il + w + 1);
+        if (nvalid == 8) { U[9] = ur; M[9] = mr; D[9] = dr; } else { U[5] = ur; M[5] = mr; D[5] = dr; }
+      }
+      float hv[8];
+      float2 gv[8];
+      const bool want_got = a.got_src != nullptr;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float v11 = U[j], v12 = U[j + 1], v13 = U[j + 2];
+        const float v21 = M[j], v22 = M[j + 1], v23 = M[j + 2];
+        const float v31 = D[j], v32 = D[j + 1], v33 = D[j + 2];
+        const float Lxx = fmaf(-2.0f, v22, v21) + v23;      // ProgramCU.cu:536
+        const float Lyy = fmaf(-2.0f, v22, v12) + v32;      // :537
+        const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;  // :538
+        hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * a.norm_src;  // :553
+        if (want_got) {
+          const float dx = v23 - v21, dy = v32 - v12;       // :556-557
+          const float gradient = 0.5f * sqrtf(fmaf(dx, dx, dy * dy));
+          gv[j].x = gradient;
+          gv[j].y = (gradient == 0.0f) ? 0.0f : dm_atan2f(dy, dx);
+        }
+      }
+      const long long o = img * (long long)w * h + idx;
+      *reinterpret_cast<float4*>(a.deth_src + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      if (nvalid == 8) *reinterpret_cast<float4*>(a.deth_src + o + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
+      if (want_got) {
+        float2* gp = a.got_src + o;
+        *reinterpret_cast<float4*>(gp) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
+        *reinterpret_cast<float4*>(gp + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
+        if (nvalid == 8) {
+          *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4].x, gv[4].y, gv[5].x, gv[5].y);
+          *reinterpret_cast<float4*>(gp + 6) = make_float4(gv[6].x, gv[6].y, gv[7].x, gv[7].y);
+        }
+      }
+    }
+  }
+
   // ---- stage 2: horizontal pass, LDS -> LDS ----
   for (int task = tid; task < ROWS * (TW / 8); task += NT) {
     int r = task >> 3, xb = (task & 7) * 8;
@@ -169,9 +252,11 @@ void launch_r(hipStream_t st, GaussArgs a, int batch) {
   const int ntile = a.tiles_x * a.tiles_y * batch;
   dim3 grid(((ntile + 7) / 8) * 8);
   if (a.src_u8)
-    hipLaunchKernelGGL((gauss_kernel<R, true>), grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((gauss_kernel<R, true, false>), grid, dim3(NT), 0, st, a);
+  else if (a.deth_src)
+    hipLaunchKernelGGL((gauss_kernel<R, false, true>), grid, dim3(NT), 0, st, a);
   else
-    hipLaunchKernelGGL((gauss_kernel<R, false>), grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((gauss_kernel<R, false, false>), grid, dim3(NT), 0, st, a);
 }
 
 // ---- input conversion (GLTexImage.cpp:802-916): any format/type -> float luminance ----
@@ -232,10 +317,12 @@ __global__ __launch_bounds__(256) void downsample_kernel(const float* src, int s
 }  // namespace
 
 void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
-                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps) {
+                  long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
+                  float* deth_src, float* got_src, float norm_src) {
   GaussArgs a;
   a.src = src; a.src_u8 = src_u8; a.src_pitch = src_pitch; a.src_img_stride = src_img_stride;
   a.dst = dst; a.w = wa; a.h = h; a.taps = taps;
+  a.deth_src = deth_src; a.got_src = reinterpret_cast<float2*>(got_src); a.norm_src = norm_src;
   switch (taps.fw >> 1) {
     case 2: launch_r<2>(st, a, batch); break;
     case 3: launch_r<3>(st, a, batch); break;
