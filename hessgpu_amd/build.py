@@ -62,6 +62,17 @@ def build_all(force=False, verbose=False):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include"),
                   api_src, "-o", api, "-L", HERE, "-lhessgpu", "-Wl,-rpath,$ORIGIN"])
         built.append(api)
+        apps_dir = os.path.join(HERE, "..", "apps")
+        bindir = os.path.join(HERE, "bin")
+        os.makedirs(bindir, exist_ok=True)
+        for app in ("hess", "speed"):
+            src = os.path.join(apps_dir, app + ".cpp")
+            exe = os.path.join(bindir, app)
+            if os.path.exists(src) and (force or _newer([src, api_hdr, api], exe)):
+                _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(HERE, "..", "include"), src, "-o", exe,
+                      "-L", HERE, "-lsiftgpu", "-lhessgpu", "-Wl,-rpath,$ORIGIN/.."])
+            if os.path.exists(exe):
+                built.append(exe)
     if verbose:
         print("built:", *built)
     return built

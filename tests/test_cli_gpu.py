@@ -1,0 +1,55 @@
+"""The `hess` batch tool and the `speed` harness (apps/, reference: src/HessGPU/hessgpucmd.cpp,
+src/TestWin/speed.cpp) end to end on the GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fixtures
+from oracle_lib import OracleSession
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hessgpu_amd", "bin")
+
+
+def _write_pgm(path, lum):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (lum.shape[1], lum.shape[0]))
+        f.write(lum.tobytes())
+
+
+def test_hess_cli_list_mode_writes_sift_and_timings(tmp_path):
+    names = ["640-4.jpg", "640-5.jpg"]
+    lums = [fixtures.load_rgb(n)[..., 1].copy() for n in names]
+    for n, l in zip(names, lums):
+        _write_pgm(tmp_path / (n[:-4] + ".pgm"), l)
+    (tmp_path / "list.txt").write_text("640-4.pgm\n640-5.pgm\n")
+    r = subprocess.run([os.path.join(BIN, "hess"), "-il", str(tmp_path / "list.txt"), "-time", "-topk", "300"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    o = OracleSession(threads=8, keep_levels=False, truncate_method=3, feature_count_threshold=300)
+    for n, l in zip(names, lums):
+        base = tmp_path / (n[:-4] + ".pgm")
+        tok = open(str(base) + ".sift").read().split()
+        o.run(l[None])
+        k, d = o.fetch(0)
+        assert int(tok[0]) == len(k) and int(tok[1]) == 128
+        first = [int(v) for v in tok[2 + 7: 2 + 7 + 128]]
+        assert first == [int(np.floor(0.5 + 512.0 * v)) for v in d[0]]
+        t = [float(v) for v in open(str(base) + ".timings").read().split(",")]
+        assert len(t) == 11 and t[-1] > 0 and t[2] > 0  # total, pyramid
+
+
+def test_hess_cli_usage_without_images():
+    r = subprocess.run([os.path.join(BIN, "hess")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "-il" in r.stdout
+
+
+def test_speed_harness_reports_stable_counts(tmp_path):
+    lum = fixtures.load_rgb("640-1.jpg")[..., 1].copy()
+    _write_pgm(tmp_path / "a.pgm", lum)
+    r = subprocess.run([os.path.join(BIN, "speed"), "-i", str(tmp_path / "a.pgm"), "-n", "5"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "+++++" in r.stdout and "e" not in r.stdout.splitlines()[0] and "Hz" in r.stdout
