@@ -94,6 +94,8 @@ PROTOTYPES = {
     "destroy": (None, [_ctx]),
     "run_host": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                            C.c_int, C.c_int]),
+    "set_keypoints": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "run_keypoints": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "count": (C.c_int, [_ctx, C.c_int]),
     "desc_dim": (C.c_int, [_ctx]),
     "fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p]),

@@ -81,6 +81,7 @@ struct OrientParams {
   float ln_sigma_step;
   int num_orientation;  // 0 (-ofix), 1 (-m 1), >1 multi
   int subpixel, half_sift;
+  int existing;         // 1: user keypoints -- position/scale from the packed record, only .w is written
   float level_sigma[kMaxLev];
 };
 

@@ -10,6 +10,7 @@
 // counts followed by one of the results; feature-list order is deterministic (level, row, col).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +82,14 @@ struct hess_ctx {
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
+  // user-supplied keypoint list (SiftPyramid::SetKeypointList): used by the next run, then cleared
+  std::vector<hess_keypoint> user_keys;
+  bool user_have_orientation = false;
+  bool user_on_current = false;     // RunSIFT(num, keys, flag): skip filtering, reuse the resident pyramid
+  std::vector<int> user_kindex;     // list position -> input index (_keypoint_index)
+  bool user_result = false;         // last results are in u_keys / u_desc (input order)
+  std::vector<hess_keypoint> u_keys;
+  std::vector<float> u_desc;
   const RawKey* d_list = nullptr;  // list fed to the orientation stage in the last run
   const int* d_list_total = nullptr;
   int cap_list = 0;
@@ -245,7 +254,8 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   }
   ws &= ~3;  // TruncateWidthCU
   if (ws < 4 || hs < 1) { set_err(c, "image too small"); return HESS_ERR_ARG; }
-  const bool same = c->planned && c->in_w == width && c->in_h == height && batch <= c->g.B;
+  const bool same = c->planned && c->in_w == width && c->in_h == height && batch <= c->g.B &&
+                    (int)(2 * c->user_keys.size() + 8) <= c->cap_sel && (int)(2 * c->user_keys.size() + 8) <= c->cap_feat;
   if (same) return 0;
   const int B = (c->planned && c->g.B > batch) ? c->g.B : batch;
 
@@ -291,10 +301,16 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   long long det_px = gt / B;  // detection pixels per image
   int cap_raw = (int)(det_px / 32 < 16384 ? 16384 : det_px / 32);
   if (cap_raw < c->cap_raw) cap_raw = c->cap_raw;
+  if (cap_raw < (int)(2 * c->user_keys.size() + 8)) cap_raw = (int)(2 * c->user_keys.size() + 8);
   int cap_sel = c->use_topk ? p.feature_count_threshold : cap_raw;
   if (cap_sel > cap_raw) cap_sel = cap_raw;
   int cap_feat = c->multi ? (c->use_topk ? 4 * cap_sel : cap_sel) : cap_sel;
   if (cap_feat < c->cap_feat) cap_feat = c->cap_feat;
+  if (!c->user_keys.empty()) {  // a keypoint list bypasses top-K: every stage must hold 2*num+8 records
+    const int need = (int)(2 * c->user_keys.size() + 8);
+    if (cap_sel < need) cap_sel = need;
+    if (cap_feat < need) cap_feat = need;
+  }
 
   int rc;
   if ((rc = ensure(c, c->gauss, (size_t)lvl * 4))) return rc;
@@ -377,6 +393,8 @@ void drain_profile(hess_ctx* c) {
   c->pending.clear();
 }
 
+int enqueue_user(hess_ctx* c);
+
 // Enqueue the whole path for `batch` images whose pixels are at device address `dev`.
 int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int batch, int format, int pixtype) {
   const hess_params& p = c->p;
@@ -389,6 +407,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   auto plane_ptr = [&](float* base, int o, int l) { return base + g.o[o].lvl_off + (long long)l * g.B * g.o[o].plane; };
 
   (void)hipEventRecord(c->ev[0], st);
+  const bool user_mode = !c->user_keys.empty();
+  if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
   // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
   const bool direct_u8 = (format == HESS_FMT_LUM && pixtype == HESS_PIX_U8 && c->ds == 0 && c->has_taps0 &&
                           (pitch % 4) == 0 && (image_stride % 4) == 0 && ((uintptr_t)dev % 4) == 0);
@@ -434,6 +454,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_HESSIAN, (double)batch * g.o[o].plane * 8.0);
     launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
   }
+  }  // !(user_mode && on_current)
+  if (user_mode) return enqueue_user(c);
   // ---- extrema + ordered list (DetectKeypointsEX part 2 + GenerateFeatureList) ----
   DetectParams dp;
   dp.thr = p.dog_threshold;
@@ -485,6 +507,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   op.num_orientation = p.fixed_orientation ? 0 : p.max_orientation;      // ProgramCU.cu:1639
   op.subpixel = p.subpixel;
   op.half_sift = p.half_sift;
+  op.existing = 0;
   for (int l = 0; l < kMaxLev; l++) op.level_sigma[l] = l <= s.level_max ? s.level_sigma[l] : 0.0f;
   {
     ProfScope ps(c, HESS_K_ORIENT, 0.0);
@@ -516,8 +539,120 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   return 0;
 }
 
+// FLOAT_TO_FIXED_POINT (config.h:73-74), host version.
+static inline int float_to_fixed_host(float v, int n) {
+  return (int)((double)(v * (float)(1 << n)) + ((v >= 0.0) ? 0.5 : -0.5));
+}
+
+// User-supplied keypoints (PyramidCU::GenerateFeatureListTex, PyramidCU.cpp:555-718): bin the keys to
+// levels by scale, pack fixed-point records on the host, upload, strongest orientation on the device
+// unless supplied, descriptors.  One image.
+int enqueue_user(hess_ctx* c) {
+  const hess_params& p = c->p;
+  const Schedule& s = c->sch;
+  const Geom& g = c->g;
+  hipStream_t st = c->st;
+  const int num = (int)c->user_keys.size();
+  const double twopi = 2.0 * 3.14159265358979323846;
+  const float sigma_half_step = powf(2.0f, 0.5f / g.dog);
+  float octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+  const float offset = p.lowe_origin ? 0.0f : 0.5f;
+  std::vector<RawKey> hl;
+  std::vector<FRec> hr;
+  c->user_kindex.clear();
+  const size_t cap = 2 * (size_t)num + 8;
+  for (int octave = 0; octave < g.noct; octave++, octave_sigma *= 2.0f) {
+    for (int level = 1; level <= g.dog; level++) {
+      const float level_sigma = s.level_sigma[level] * octave_sigma;
+      const float sigma_min = level_sigma / sigma_half_step;
+      const float sigma_max = level_sigma * sigma_half_step;
+      for (int k = 0; k < num && hl.size() < cap; k++) {
+        const hess_keypoint& key = c->user_keys[k];
+        const float sigmak = key.s;
+        if (((sigmak >= sigma_min) && (sigmak < sigma_max)) || ((sigmak < sigma_min) && (octave == 0) && (level == 1)) ||
+            ((sigmak > sigma_max) && (octave == g.noct - 1) && (level == g.dog))) {
+          const float fX = (key.x - offset) / octave_sigma + 0.5f;
+          const float fY = (key.y - offset) / octave_sigma + 0.5f;
+          const float fScale = key.s / octave_sigma;
+          const float fOrientation = (float)fmod(twopi - key.o, twopi);
+          FRec r;
+          r.x = (uint32_t)float_to_fixed_host(fX, 10) & 0x00FFFFFFu;
+          r.y = (uint32_t)float_to_fixed_host(fY, 10) & 0x00FFFFFFu;
+          r.z = (uint32_t)float_to_fixed_host(fScale, 8) & 0x0000FFFFu;
+          memcpy(&r.w, &fOrientation, 4);
+          RawKey rk;
+          memset(&rk, 0, sizeof(rk));
+          rk.level_index = octave * g.dog + (level - 1);
+          hl.push_back(rk);
+          hr.push_back(r);
+          c->user_kindex.push_back(k);
+        }
+      }
+    }
+  }
+  const int n = (int)hl.size();
+  if (n > c->cap_raw || n > c->cap_sel || n > c->cap_feat) {
+    set_err(c, "keypoint list (%d) exceeds the reserved feature storage", n);
+    return HESS_ERR_NOMEM;  // plan() sizes storage for 2*num+8 when a list is set
+  }
+  int* hs = (int*)c->h_small.p;
+  hs[3 * g.B + 4] = n;
+  (void)hipMemsetAsync(c->overflow.p, 0, 16, st);
+  if (n) {
+    HIP_TRY(c, hipMemcpyAsync(c->raw.p, hl.data(), (size_t)n * sizeof(RawKey), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->recs.p, hr.data(), (size_t)n * sizeof(FRec), hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->raw_total.p, hs + 3 * g.B + 4, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipStreamSynchronize(st));  // hl/hr are pageable host vectors: finish before they go away
+  const RawKey* list = (const RawKey*)c->raw.p;
+  const int* list_total = (const int*)c->raw_total.p;
+  c->d_list = list;
+  c->d_list_total = list_total;
+  c->cap_list = c->cap_raw;
+  for (int e = 1; e <= 4; e++) (void)hipEventRecord(c->ev[e], st);
+  float* got = (float*)c->got.p;
+  if (!c->user_have_orientation) {
+    OrientParams op;
+    op.gaussian_factor = p.orient_gaussian_factor;
+    op.sample_factor = p.orient_gaussian_factor * p.orient_window_factor;
+    op.ln_sigma_step = s.ln_sigma_step;
+    op.num_orientation = p.fixed_orientation ? 0 : p.max_orientation;
+    op.subpixel = 0;
+    op.half_sift = p.half_sift;
+    op.existing = 1;
+    for (int l = 0; l < kMaxLev; l++) op.level_sigma[l] = l <= s.level_max ? s.level_sigma[l] : 0.0f;
+    launch_orientation(st, g, op, list, list_total, c->cap_raw, got, (FRec*)c->recs.p, (int*)c->ocount.p, 1);
+  }
+  (void)hipEventRecord(c->ev[5], st);
+  LimitParams lp;
+  lp.method = 0;
+  lp.threshold = -1;  // LimitFeatureCount returns at once for existing keypoints (SiftPyramid.cpp:203)
+  launch_feature_scan(st, g, lp, 0, list, list_total, c->cap_raw, (const int*)c->ocount.p, (int*)c->foffset.p,
+                      (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
+                      (int*)c->overflow.p + 1, 1);
+  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, 1);
+  (void)hipEventRecord(c->ev[6], st);
+  DescParams dsp;
+  dsp.window_factor = p.desc_window_factor;
+  dsp.half_sift = p.half_sift;
+  dsp.normalize = p.normalize;
+  dsp.multi = 0;
+  dsp.lowe_origin = p.lowe_origin;
+  dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+  dsp.dog = g.dog;
+  launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
+                    (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
+                    (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
+  (void)hipEventRecord(c->ev[7], st);
+  return 0;
+}
+
 // Enqueue the whole path and the copy of the per-image counts; returns without waiting.
 int submit_impl(hess_ctx* c, const PendingRun& r) {
+  if (!c->user_keys.empty() && r.batch != 1) {
+    set_err(c, "a keypoint list applies to a single image");
+    return HESS_ERR_ARG;
+  }
   int rc = plan(c, r.width, r.height, r.batch);
   if (rc) return rc;
   int* hs = (int*)c->h_small.p;
@@ -564,6 +699,26 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
     if (c->dim)
       HIP_TRY(c, hipMemcpyAsync(c->h_desc.p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
+  }
+  c->user_result = false;
+  if (!c->user_keys.empty()) {
+    // back to input order (PyramidCU.cpp:537-549,1157-1168); the caller's keypoints are returned
+    // unchanged unless DownloadKeypoints would run (-m 1 / -ofix, SiftPyramid.cpp:160-171)
+    const int num = (int)c->user_keys.size();
+    const int listed = (int)std::min<size_t>(total, (size_t)num);
+    const bool download = !c->user_have_orientation && ((c->p.max_orientation < 2) || c->p.fixed_orientation);
+    c->u_keys = c->user_keys;
+    c->u_desc.assign((size_t)num * (c->dim ? c->dim : 1), 0.0f);
+    for (int i = 0; i < listed; i++) {
+      const int k = c->user_kindex[i];
+      if (download) memcpy(&c->u_keys[k], (HostKeypoint*)c->h_keys.p + i, sizeof(hess_keypoint));
+      if (c->dim) memcpy(&c->u_desc[(size_t)k * c->dim], (float*)c->h_desc.p + (size_t)i * c->dim, (size_t)c->dim * 4);
+    }
+    c->counts[0] = num;
+    c->offs[1] = (size_t)num;
+    c->user_result = true;
+    c->user_keys.clear();  // _existing_keypoints = 0 after RunSIFT (SiftPyramid.cpp:182-184)
+    c->user_on_current = false;
   }
   // stage times from the events of the last enqueue (config.h:17-31 order)
   memset(c->timing, 0, sizeof(c->timing));
@@ -708,6 +863,32 @@ int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pi
   return wait_impl(c, *c->pend);
 }
 
+int hess_set_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
+  if (!c || num < 0 || (num > 0 && !keys)) return HESS_ERR_ARG;
+  c->user_keys.assign(keys, keys + num);
+  c->user_have_orientation = keys_have_orientation != 0;
+  c->user_on_current = false;
+  return 0;
+}
+
+int hess_run_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
+  if (!c || num <= 0 || !keys) return HESS_ERR_ARG;
+  if (!c->planned || c->batch < 1) { set_err(c, "no current image: run an image first"); return HESS_ERR_STATE; }
+  if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->user_keys.assign(keys, keys + num);
+  c->user_have_orientation = keys_have_orientation != 0;
+  c->user_on_current = true;
+  if (!c->pend) c->pend = new PendingRun();
+  PendingRun r = *c->pend;  // geometry of the current image
+  if (r.width <= 0) { c->user_keys.clear(); set_err(c, "no current image"); return HESS_ERR_STATE; }
+  r.batch = 1;
+  r.t_load_ms = 0.0;
+  int rc = submit_impl(c, r);
+  if (rc) { c->user_keys.clear(); return rc; }
+  return wait_impl(c, r);
+}
+
 int hess_count(hess_ctx* c, int img) {
   if (!c || img < 0 || img >= c->batch) return HESS_ERR_ARG;
   return c->counts[img];
@@ -718,6 +899,11 @@ int hess_desc_dim(hess_ctx* c) { return c ? c->dim : HESS_ERR_ARG; }
 int hess_fetch(hess_ctx* c, int img, hess_keypoint* keys, float* desc) {
   if (!c || img < 0 || img >= c->batch) return HESS_ERR_ARG;
   const size_t n = (size_t)c->counts[img];
+  if (c->user_result) {
+    if (keys && n) memcpy(keys, c->u_keys.data(), n * sizeof(hess_keypoint));
+    if (desc && c->dim && n) memcpy(desc, c->u_desc.data(), n * c->dim * 4);
+    return 0;
+  }
   if (keys && n) memcpy(keys, (HostKeypoint*)c->h_keys.p + c->offs[img], n * sizeof(HostKeypoint));
   if (desc && c->dim && n) memcpy(desc, (float*)c->h_desc.p + c->offs[img] * c->dim, n * c->dim * 4);
   return 0;

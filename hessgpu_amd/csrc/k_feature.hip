@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
     const int width = og.wa, height = og.h;
 
     float kx = rk.col + 0.5f, ky = rk.row + 0.5f, kz = op.level_sigma[l];
-    if (op.subpixel) {  // ProgramCU.cu:1293-1298
+    FRec urec = {0u, 0u, 0u, 0u};
+    if (op.existing) {  // ProgramCU.cu:1246-1278: unpack position and scale from the uploaded record
+      urec = recs[(long long)b * cap_list + i];
+      kx = (float)(urec.x & 0x00FFFFFFu) / 1024.0f;
+      ky = (float)(urec.y & 0x00FFFFFFu) / 1024.0f;
+      kz = (float)(urec.z & 0x0000FFFFu) / 256.0f;
+    } else if (op.subpixel) {  // ProgramCU.cu:1293-1298
       kx += rk.dx;
       ky += rk.dy;
       kz *= dm_powf_ln(op.ln_sigma_step, rk.ds);
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
       const float nxt_raw = __shfl(vote, ln);
       const float nxt = (lane == 35) ? vote36 : nxt_raw;
 
-      if (op.num_orientation == 1) {  // ProgramCU.cu:1398-1420
+      if (op.num_orientation == 1 || op.existing) {  // ProgramCU.cu:1398-1420
         const uint64_t mm = __ballot(lane < 36 && vote == mx);
         const int index_max = __builtin_ctzll(mm);  // first index reaching the maximum
         const float p0 = rl(pre, index_max), n0 = rl(nxt, index_max), weight = mx;
@@ -181,7 +187,11 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
     } else {
       kw_bits = __float_as_uint(0.0f);
     }
-    if (lane == 0) {  // key_store_finish, ProgramCU.cu:1563-1596
+    if (lane == 0 && op.existing) {  // ProgramCU.cu:1597-1602: only the orientation is written back
+      urec.w = kw_bits;
+      recs[(long long)b * cap_list + i] = urec;
+      ocount[(long long)b * cap_list + i] = 0;
+    } else if (lane == 0) {  // key_store_finish, ProgramCU.cu:1563-1596
       uint32_t posX = (uint32_t)float_to_fixed(kx, 10) & 0x00FFFFFFu;
       uint32_t posY = (uint32_t)float_to_fixed(ky, 10) & 0x00FFFFFFu;
       posX |= (rk.packed & 0xFF000000u);

@@ -49,7 +49,8 @@ struct Impl {
   std::vector<hess_keypoint> keys;
   std::vector<float> desc;
   int nfeat = 0, dim = 0;
-  bool warned_keylist = false;
+  std::vector<hess_keypoint> pending_keys;  // SetKeypointList before the context existed / was rebuilt
+  int pending_keys_orient = 1;
 };
 
 inline Impl* I(SiftPyramid* p) { return reinterpret_cast<Impl*>(p); }
@@ -172,6 +173,23 @@ void SiftParam::ParseSiftParam() {
 
 // ------------------------------------------------------------------------------------------------
 // SiftGPU
+
+namespace {
+struct Peek0 : SiftGPU {
+  static Impl* impl(SiftGPU* s) { return I(static_cast<Peek0*>(s)->_pyramid); }
+};
+// Copy counts, keypoints, descriptors and stage times of the last run out of the context.
+void collect_results(SiftGPU* self) {
+  Impl* im = Peek0::impl(self);
+  im->nfeat = hess_count(im->ctx, 0);
+  im->dim = hess_desc_dim(im->ctx);
+  im->keys.resize(im->nfeat ? im->nfeat : 1);
+  im->desc.resize((size_t)(im->nfeat ? im->nfeat : 1) * (im->dim ? im->dim : 1));
+  hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
+  const float* t = hess_timing(im->ctx);
+  for (int k = 0; k < 12; k++) self->_timing[k] = t[k];
+}
+}  // namespace
 
 SiftGPU::SiftGPU(int np) {
   (void)np;
@@ -432,18 +450,24 @@ int SiftGPU::RunSIFT(int width, int height, const void* data, unsigned int gl_fo
   return RunSIFT();
 }
 
-int SiftGPU::RunSIFT(int num, const SiftKeypoint* keys, int keys_have_orientation) {
-  SetKeypointList(num, keys, keys_have_orientation);
-  return 0;
+int SiftGPU::RunSIFT(int num, const SiftKeypoint* keys, int keys_have_orientation) {  // SiftGPU.cpp:307-315
+  Impl* im = I(_pyramid);
+  if (num <= 0 || !keys || !im->ctx) return 0;
+  const int rc = hess_run_keypoints(im->ctx, reinterpret_cast<const hess_keypoint*>(keys), num, keys_have_orientation);
+  if (rc != 0) {
+    std::cerr << "SiftGPU: " << hess_last_error(im->ctx) << "\n";
+    return 0;
+  }
+  collect_results(this);
+  return 1;
 }
 
 void SiftGPU::SetKeypointList(int num, const SiftKeypoint* keys, int keys_have_orientation) {
-  (void)num; (void)keys; (void)keys_have_orientation;
   Impl* im = I(_pyramid);
-  if (!im->warned_keylist) {
-    std::cerr << "SiftGPU: user-supplied keypoint lists are not implemented in this build\n";
-    im->warned_keylist = true;
-  }
+  InitSiftGPU();
+  if (im->ctx) hess_set_keypoints(im->ctx, reinterpret_cast<const hess_keypoint*>(keys), num, keys_have_orientation);
+  im->pending_keys.assign(reinterpret_cast<const hess_keypoint*>(keys), reinterpret_cast<const hess_keypoint*>(keys) + (num > 0 ? num : 0));
+  im->pending_keys_orient = keys_have_orientation;
 }
 
 int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
@@ -462,6 +486,8 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
     if (im->verbose) std::cout << "Image loaded :\t" << _imgpath << "\n";
   }
   _image_loaded = 1;
+  if (!im->pending_keys.empty())
+    hess_set_keypoints(im->ctx, im->pending_keys.data(), (int)im->pending_keys.size(), im->pending_keys_orient);
   const int pitch = im->w * channels(im->fmt) * pix_bytes(im->pix);
   const int rc = hess_run_host(im->ctx, im->pixels.data(), im->w, im->h, pitch, (size_t)pitch * im->h, 1, im->fmt, im->pix);
   if (rc != 0) {
@@ -469,18 +495,13 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
     im->nfeat = 0;
     return 0;  // device errors -> 0 (SiftPyramid.h:162-163); oversize image is an error return here, not exit()
   }
-  im->nfeat = hess_count(im->ctx, 0);
-  im->dim = hess_desc_dim(im->ctx);
-  im->keys.resize(im->nfeat ? im->nfeat : 1);
-  im->desc.resize((size_t)(im->nfeat ? im->nfeat : 1) * (im->dim ? im->dim : 1));
-  hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
-  const float* t = hess_timing(im->ctx);
-  for (int k = 0; k < 12; k++) _timing[k] = t[k];
+  collect_results(this);
   if (im->verbose) {
     std::cout << "#Features:\t" << im->nfeat << "\n";
     if (im->timingS) std::cout << "RUN SIFT:\t" << _timing[TIMINGS_TOTAL] << "ms\n";
     std::cout << std::endl;
   }
+  im->pending_keys.clear();
   if (_outpath[0]) { SaveSIFT(_outpath); _outpath[0] = 0; }
   return 1;
 }
@@ -610,6 +631,8 @@ void siftgpu_save(SiftGPU* s, const char* path) { s->SaveSIFT(path); }
 const float* siftgpu_timing(SiftGPU* s) { return s->_timing; }
 void siftgpu_set_verbose(SiftGPU* s, int v) { s->SetVerbose(v); }
 int siftgpu_image_count(SiftGPU* s) { return s->GetImageCount(); }
+int siftgpu_run_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation) { return s->RunSIFT(num, keys, have_orientation); }
+void siftgpu_set_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation) { s->SetKeypointList(num, keys, have_orientation); }
 
 }  // extern "C"
 

@@ -109,6 +109,17 @@ class Session:
         """Block until the submitted batch's keypoints and descriptors are in host memory."""
         self._check(self._f["wait"](self._h))
 
+    def set_keypoints(self, keys, have_orientation=True):
+        """SiftGPU::SetKeypointList: the next run() of ONE image uses these keypoints, no detection."""
+        k = np.ascontiguousarray(keys, dtype=_abi.KEYPOINT_DTYPE)
+        self._check(self._f["set_keypoints"](self._h, k.ctypes.data_as(C.c_void_p), len(k), int(have_orientation)))
+
+    def run_keypoints(self, keys, have_orientation=True):
+        """SiftGPU::RunSIFT(num, keys, flag): orientation/descriptors for `keys` on the current image."""
+        k = np.ascontiguousarray(keys, dtype=_abi.KEYPOINT_DTYPE)
+        self._check(self._f["run_keypoints"](self._h, k.ctypes.data_as(C.c_void_p), len(k), int(have_orientation)))
+        return self.count(0)
+
     def reserve(self, width, height, batch):
         self._check(self._f["reserve"](self._h, width, height, batch))
 

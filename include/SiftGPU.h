@@ -9,7 +9,7 @@
 //
 // Not provided in this build (they return 0 / do nothing and say so on stderr once):
 //   SiftMatchGPU (descriptor matcher), ComboSiftGPU / CreateRemoteSiftGPU (TCP server mode),
-//   SiftGPUEX (viewer), user-supplied keypoint lists (SetKeypointList / RunSIFT(num, keys, ..)).
+//   SiftGPUEX (viewer), the rectangle-descriptor hack of SetKeypointList (keys_have_orientation == -1).
 #ifndef GPU_SIFT_H
 #define GPU_SIFT_H
 
@@ -182,6 +182,8 @@ void siftgpu_save(SiftGPU* s, const char* path);
 const float* siftgpu_timing(SiftGPU* s);
 void siftgpu_set_verbose(SiftGPU* s, int v);
 int siftgpu_image_count(SiftGPU* s);
+int siftgpu_run_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation);
+void siftgpu_set_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation);
 // The resolved hess_params of the instance (what ParseParam did), for tests.
 int siftgpu_get_params(SiftGPU* s, void* hess_params_out);
 int siftgpu_descriptor_dim(SiftGPU* s);

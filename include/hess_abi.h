@@ -143,6 +143,15 @@ int hess_wait(hess_ctx* ctx);
 int hess_run_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
                     size_t image_stride, int batch, int format, int pixtype);
 
+/* Replaces SiftGPU::SetKeypointList -> SiftPyramid::SetKeypointList (SiftPyramid.cpp:326-355): the
+ * NEXT hess_run_* call (one image) skips detection and computes orientation (unless
+ * keys_have_orientation) and descriptors for these keypoints (PyramidCU::GenerateFeatureListTex,
+ * PyramidCU.cpp:555-718); results come back in input order; the list is cleared afterwards. */
+int hess_set_keypoints(hess_ctx* ctx, const hess_keypoint* keys, int num, int keys_have_orientation);
+/* Replaces SiftGPU::RunSIFT(num, keys, keys_have_orientation) (SiftGPU.cpp:307-315): the same on the
+ * CURRENT image (first image of the last run) without rebuilding the pyramid. */
+int hess_run_keypoints(hess_ctx* ctx, const hess_keypoint* keys, int num, int keys_have_orientation);
+
 /* Replaces SiftGPU::GetFeatureNum (SiftGPU.cpp:1551-1554) for image `img` of the last batch. */
 int hess_count(hess_ctx* ctx, int img);
 /* Descriptor length of the last run: 128, 64 (-half) or 0 (-sd). */

@@ -71,6 +71,9 @@ struct hess_cpu_ctx {
   image_result* res;
   int desc_dim;
   int threads, keep;
+  /* user-supplied keypoint list for the next run (SiftPyramid::SetKeypointList) */
+  hess_keypoint* user_keys;
+  int user_num, user_have_orientation;
   float timing[HESS_T_COUNT];
   char err[256];
 };
@@ -515,6 +518,68 @@ static void compute_orientation(const hess_cpu_ctx* c, const hess_rawkey* rk, co
   out->x = posX; out->y = posY; out->z = scale; out->w = kw_bits;
 }
 
+/* ComputeOrientation_Kernel with existing_keypoint = 1 (ProgramCU.cu:1246-1278,1398-1420,1597-1602):
+ * position and scale come from the packed record, sub-pixel offsets are not applied, only the
+ * strongest orientation is kept as a float angle in record.w; x, y, z stay as uploaded. */
+static void compute_orientation_existing(const hess_cpu_ctx* c, frec* rec, const float* got, int width,
+                                         int height) {
+  const float ten_degree_per_radius = 5.7295779513082320876798154814105f;
+  const float radius_per_ten_degrees = (float)(1.0 / 5.7295779513082320876798154814105);
+  const hess_params* p = &c->p;
+  int num_orientation = p->fixed_orientation ? 0 : p->max_orientation;
+  float kx = FIXED_TO_FLOAT(rec->x & 0x00FFFFFFu, 10);
+  float ky = FIXED_TO_FLOAT(rec->y & 0x00FFFFFFu, 10);
+  float kz = FIXED_TO_FLOAT(rec->z & 0x0000FFFFu, 8);
+  if (num_orientation == 0) { rec->w = om_f2u(0.0f); return; }
+  float vote[37];
+  float gsigma = kz * p->orient_gaussian_factor;
+  float win = fabsf(kz) * (p->orient_gaussian_factor * p->orient_window_factor);
+  float dist_threshold = win * win + 0.5f;
+  float factor = -0.5f / (gsigma * gsigma);
+  float xmin = fmaxf(1.5f, floorf(kx - win) + 0.5f);
+  float ymin = fmaxf(1.5f, floorf(ky - win) + 0.5f);
+  float xmax = fminf(width - 1.5f, floorf(kx + win) + 0.5f);
+  float ymax = fminf(height - 1.5f, floorf(ky + win) + 0.5f);
+  for (int i = 0; i < 36; ++i) vote[i] = 0.0f;
+  for (float y = ymin; y <= ymax; y += 1.0f) {
+    float dy = y - ky;
+    dy *= dy;
+    for (float x = xmin; x <= xmax; x += 1.0f) {
+      float dx = x - kx;
+      float sq_dist = fmaf(dx, dx, dy);
+      if (sq_dist >= dist_threshold) continue;
+      const float* g = got + 2 * ((long)(int)y * width + (int)x);
+      int oidx = (int)floorf(g[1] * ten_degree_per_radius);
+      if (oidx < 0) oidx += 36;
+      vote[oidx] = fmaf(g[0], om_expf(sq_dist * factor), vote[oidx]);
+    }
+  }
+  const float one_third = (float)(1.0 / 3.0);
+  for (int i = 0; i < 6; ++i) {
+    vote[36] = vote[0];
+    float pre = vote[35];
+    for (int j = 0; j < 36; ++j) {
+      float temp = one_third * (pre + vote[j] + vote[j + 1]);
+      pre = vote[j];
+      vote[j] = temp;
+    }
+  }
+  vote[36] = vote[0];
+  if (p->half_sift)
+    for (int i = 0; i < 18; i++) { vote[i] += vote[i + 18]; vote[i + 18] = 0; }
+  int index_max = 0;
+  float max_vote = vote[0];
+  for (int i = 1; i < 36; ++i) {
+    index_max = (vote[i] > max_vote) ? i : index_max;
+    max_vote = fmaxf(max_vote, vote[i]);
+  }
+  float pre = vote[(index_max == 0) ? 35 : index_max - 1];
+  float next = vote[index_max + 1];
+  float weight = max_vote;
+  float off = 0.5f * ((next - pre) / (weight + weight - next - pre));
+  rec->w = om_f2u(radius_per_ten_degrees * (index_max + 0.5f + off));
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* ComputeDescriptor_Kernel<false,HALF>, ProgramCU.cu:1650-1804 + NormalizeDescriptor_Kernel
  * :1950-2054.  `angle` is the un-mirrored float orientation handed to the kernel (key.w).    */
@@ -639,6 +704,7 @@ hess_cpu_ctx* hess_cpu_create(const hess_params* params) {
 void hess_cpu_destroy(hess_cpu_ctx* c) {
   if (!c) return;
   free_results(c);
+  free(c->user_keys);
   free(c);
 }
 void hess_cpu_set_threads(hess_cpu_ctx* c, int t) { c->threads = t < 1 ? 1 : t; }
@@ -705,6 +771,105 @@ static int tk_cmp(const void* a, const void* b) {
   if (x->key > y->key) return -1;
   if (x->key < y->key) return 1;
   return x->idx - y->idx;
+}
+
+/* User-supplied keypoints: PyramidCU::GenerateFeatureListTex (PyramidCU.cpp:555-718) bins the keys to
+ * levels by scale (half-step bounds, first/last level catch the rest) and packs fixed-point records in
+ * input order per level; orientation (strongest only) unless the keys carry one; descriptors; results
+ * put back in input order through _keypoint_index (PyramidCU.cpp:537-549,1157-1168).  The pyramid
+ * (gradient planes) of R must exist. */
+static int user_keypoint_path(hess_cpu_ctx* c, image_result* R) {
+  const hess_params* p = &c->p;
+  const int dog = p->dog_level_num, num = c->user_num;
+  const hess_keypoint* uk = c->user_keys;
+  pyramid* py = &R->pyr;
+  const double twopi = 2.0 * PI_D;
+  float sigma_half_step = powf(2.0f, 0.5f / dog);
+  float octave_sigma = 1.0f;
+  if (c->ds > 0) octave_sigma *= (float)(1 << c->ds);
+  float offset = p->lowe_origin ? 0.0f : 0.5f;
+  int cap = 2 * num + 8;
+  frec* recs = (frec*)malloc((size_t)cap * sizeof(frec));
+  int* rlevel = (int*)malloc((size_t)cap * sizeof(int));
+  int* kindex = (int*)malloc((size_t)cap * sizeof(int));
+  if (!recs || !rlevel || !kindex) return HESS_ERR_NOMEM;
+  int n = 0;
+  for (int octave = 0; octave < c->noct; octave++, octave_sigma *= 2.0f) {
+    for (int level = 1; level <= dog; level++) {
+      float level_sigma = c->level_sigma[level] * octave_sigma;
+      float sigma_min = level_sigma / sigma_half_step;
+      float sigma_max = level_sigma * sigma_half_step;
+      for (int k = 0; k < num && n < cap; k++) {
+        float sigmak = uk[k].s;
+        if (((sigmak >= sigma_min) && (sigmak < sigma_max)) || ((sigmak < sigma_min) && (octave == 0) && (level == 1)) ||
+            ((sigmak > sigma_max) && (octave == c->noct - 1) && (level == dog))) {
+          float fX = (uk[k].x - offset) / octave_sigma + 0.5f;
+          float fY = (uk[k].y - offset) / octave_sigma + 0.5f;
+          float fScale = uk[k].s / octave_sigma;
+          float fOrientation = (float)fmod(twopi - uk[k].o, twopi);
+          recs[n].x = (uint32_t)FLOAT_TO_FIXED(fX, 10) & 0x00FFFFFFu;
+          recs[n].y = (uint32_t)FLOAT_TO_FIXED(fY, 10) & 0x00FFFFFFu;
+          recs[n].z = (uint32_t)FLOAT_TO_FIXED(fScale, 8) & 0x0000FFFFu;
+          recs[n].w = om_f2u(fOrientation);
+          rlevel[n] = octave * dog + (level - 1);
+          kindex[n] = k;
+          n++;
+        }
+      }
+    }
+  }
+  /* orientation: SiftPyramid.cpp:128-137 (skipped when the keys have one; _MaxOrientation > 0 always) */
+  if (!c->user_have_orientation) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+      int o = rlevel[i] / dog, l = rlevel[i] % dog + 1;
+      compute_orientation_existing(c, &recs[i], py->got[o][l], c->g[o].wa, c->g[o].h);
+    }
+  }
+  /* keypoints: the caller's records unless DownloadKeypoints runs (SiftPyramid.cpp:160-171) */
+  R->n = num;
+  R->keys = (hess_keypoint*)malloc((size_t)(num ? num : 1) * sizeof(hess_keypoint));
+  memcpy(R->keys, uk, (size_t)num * sizeof(hess_keypoint));
+  int download = !c->user_have_orientation && ((p->max_orientation < 2) || p->fixed_orientation);
+  int listed = n < num ? n : num;
+  if (download) {
+    float os = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+    for (int i = 0; i < listed; i++) {
+      int li = rlevel[i];
+      float oss = os * (float)(1 << (li / dog));
+      hess_keypoint* d = &R->keys[kindex[i]];
+      float posX = FIXED_TO_FLOAT(recs[i].x & 0x00FFFFFFu, 10);
+      float posY = FIXED_TO_FLOAT(recs[i].y & 0x00FFFFFFu, 10);
+      float scale = FIXED_TO_FLOAT(recs[i].z & 0x0000FFFFu, 8);
+      d->x = oss * (posX - 0.5f) + offset;
+      d->y = oss * (posY - 0.5f) + offset;
+      d->s = oss * scale;
+      d->o = (float)fmod(twopi - om_u2f(recs[i].w), twopi);
+      d->response = om_h2f(0);
+      d->level = (uint16_t)li;
+      d->type = 0;
+    }
+  }
+  int dim = p->compute_descriptors ? (p->half_sift ? 64 : 128) : 0;
+  c->desc_dim = dim;
+  R->desc = NULL;
+  if (dim) {
+    R->desc = (float*)calloc((size_t)(num ? num : 1) * dim, sizeof(float));
+    float* tmp = (float*)malloc((size_t)(n ? n : 1) * dim * sizeof(float));
+    if (!R->desc || !tmp) return HESS_ERR_NOMEM;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n; i++) {
+      int o = rlevel[i] / dog, l = rlevel[i] % dog + 1;
+      compute_descriptor(c, &recs[i], om_u2f(recs[i].w), py->got[o][l], c->g[o].wa, c->g[o].h, tmp + (size_t)i * dim);
+    }
+    for (int i = 0; i < listed; i++) memcpy(R->desc + (size_t)kindex[i] * dim, tmp + (size_t)i * dim, (size_t)dim * 4);
+    free(tmp);
+  }
+  R->nraw = 0;
+  free(R->raw);
+  R->raw = (hess_rawkey*)malloc(sizeof(hess_rawkey));
+  free(recs); free(rlevel); free(kindex);
+  return 0;
 }
 
 static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, int height, int pitch,
@@ -787,6 +952,11 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
       float ls = c->level_sigma[l] * 1.0f; /* octaveSigma = 1, PyramidCU.cpp:1574-1585 */
       compute_hessian(py->gauss[o][l], py->deth[o][l], py->got[o][l], c->g[o].wa, c->g[o].h, ls * ls);
     }
+  if (c->user_num > 0) { /* SIFT_SKIP_DETECTION: ComputeGradient + GenerateFeatureListTex */
+    int rc = user_keypoint_path(c, R);
+    if (!c->keep) { free_pyramid(c, py); R->have_pyr = 0; }
+    return rc;
+  }
   float Tdog = p->dog_threshold;
   float Tdog1 = (p->subpixel ? 0.8f : 1.0f) * Tdog;                         /* ProgramCU.cu:897 */
   float Tedge = (p->edge_threshold + 1) * (p->edge_threshold + 1) / p->edge_threshold; /* :913 */
@@ -1005,7 +1175,37 @@ int hess_cpu_run_host(hess_cpu_ctx* c, const void* pixels, int width, int height
     if (rc) { snprintf(c->err, sizeof(c->err), "image %d failed (%d)", b, rc); return rc; }
   }
   c->timing[HESS_T_TOTAL] = (float)(now_ms() - t0);
+  hess_cpu_set_keypoints(c, NULL, 0, 0); /* _existing_keypoints = 0 after RunSIFT, SiftPyramid.cpp:182-184 */
   return 0;
+}
+
+int hess_cpu_set_keypoints(hess_cpu_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
+  if (!c || num < 0 || (num > 0 && !keys)) return HESS_ERR_ARG;
+  free(c->user_keys);
+  c->user_keys = NULL;
+  c->user_num = 0;
+  if (num > 0) {
+    c->user_keys = (hess_keypoint*)malloc((size_t)num * sizeof(hess_keypoint));
+    if (!c->user_keys) return HESS_ERR_NOMEM;
+    memcpy(c->user_keys, keys, (size_t)num * sizeof(hess_keypoint));
+    c->user_num = num;
+    c->user_have_orientation = keys_have_orientation != 0;
+  }
+  return 0;
+}
+
+/* SiftGPU::RunSIFT(num, keys, flag) (SiftGPU.cpp:307-315): same image, pyramid not rebuilt. */
+int hess_cpu_run_keypoints(hess_cpu_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
+  if (!c || num <= 0 || !keys) return HESS_ERR_ARG;
+  if (!c->res || c->batch < 1 || !c->res[0].have_pyr) { snprintf(c->err, sizeof(c->err), "no current image"); return HESS_ERR_STATE; }
+  int rc = hess_cpu_set_keypoints(c, keys, num, keys_have_orientation);
+  if (rc) return rc;
+  image_result* R = &c->res[0];
+  free(R->keys); free(R->desc);
+  R->keys = NULL; R->desc = NULL;
+  rc = user_keypoint_path(c, R);
+  hess_cpu_set_keypoints(c, NULL, 0, 0);
+  return rc;
 }
 
 int hess_cpu_count(hess_cpu_ctx* c, int img) {

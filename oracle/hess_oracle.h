@@ -36,6 +36,8 @@ void hess_cpu_keep_levels(hess_cpu_ctx* ctx, int on);
 
 int hess_cpu_run_host(hess_cpu_ctx* ctx, const void* pixels, int width, int height, int pitch,
                       size_t image_stride, int batch, int format, int pixtype);
+int hess_cpu_set_keypoints(hess_cpu_ctx* ctx, const hess_keypoint* keys, int num, int keys_have_orientation);
+int hess_cpu_run_keypoints(hess_cpu_ctx* ctx, const hess_keypoint* keys, int num, int keys_have_orientation);
 int hess_cpu_count(hess_cpu_ctx* ctx, int img);
 int hess_cpu_desc_dim(hess_cpu_ctx* ctx);
 int hess_cpu_fetch(hess_cpu_ctx* ctx, int img, hess_keypoint* keys, float* desc);

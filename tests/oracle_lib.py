@@ -28,7 +28,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _fns = _abi.bind(_lib, "hess_cpu_", _abi.PROTOTYPES)
-        _lib.hess_cpu_create.restype = C.c_void_p
+        _lib.hess_cpu_create.restype = C.c_void_p  # (set/run_keypoints are bound through _abi.PROTOTYPES)
         _lib.hess_cpu_create.argtypes = [C.POINTER(_abi.HessParams)]
         _lib.hess_cpu_set_threads.argtypes = [C.c_void_p, C.c_int]
         _lib.hess_cpu_keep_levels.argtypes = [C.c_void_p, C.c_int]

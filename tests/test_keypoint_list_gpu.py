@@ -1,0 +1,97 @@
+"""User-supplied keypoint lists: SiftGPU::SetKeypointList / RunSIFT(num, keys, flag)
+-> hess_set_keypoints / hess_run_keypoints, HIP path against the oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+import fixtures
+from hessgpu_amd import _abi
+from oracle_lib import OracleSession
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(gpu_ctx_factory, **kw):
+    return gpu_ctx_factory(**kw), OracleSession(threads=8, **kw)
+
+
+def _same(g, o, what):
+    gk, gd = g.fetch(0)
+    ok, od = o.fetch(0)
+    assert len(gk) == len(ok) > 0, what
+    assert gk.tobytes() == ok.tobytes(), f"{what}: keypoints differ"
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), f"{what}: descriptors differ"
+
+
+@pytest.mark.parametrize("have_orientation", [1, 0])
+@pytest.mark.parametrize("kw", [dict(), dict(max_orientation=1), dict(half_sift=1), dict(fixed_orientation=1)])
+def test_run_keypoints_on_current_image(gpu_ctx_factory, kw, have_orientation):
+    img = fixtures.load_rgb("640-1.jpg")
+    g, o = _pair(gpu_ctx_factory, **kw)
+    g.run(img[None]); o.run(img[None])
+    keys, _ = o.fetch(0)
+    # perturb scales so that some keys change level and the first/last level catch-alls are hit
+    keys = keys.copy()
+    keys["s"][::7] *= 3.1
+    keys["s"][3::11] *= 0.2
+    keys["s"][5] = 400.0
+    assert g.run_keypoints(keys, have_orientation) == o.run_keypoints(keys, have_orientation) == len(keys)
+    _same(g, o, f"run_keypoints {kw} orient={have_orientation}")
+    gk, _ = g.fetch(0)
+    if have_orientation or not (kw.get("max_orientation") == 1 or kw.get("fixed_orientation")):
+        assert gk.tobytes() == keys.tobytes()  # the caller's keypoints come back unchanged
+    # the list is consumed: the next plain run detects again
+    assert g.run(img[None]) == o.run(img[None])
+    _same(g, o, "detection after a keypoint run")
+
+
+def test_set_keypoints_then_run_on_another_image(gpu_ctx_factory):
+    a, b = fixtures.load_rgb("640-2.jpg"), fixtures.load_rgb("640-3.jpg")
+    g, o = _pair(gpu_ctx_factory)
+    g.run(a[None]); o.run(a[None])
+    keys, _ = o.fetch(0)
+    keys = keys[:300]
+    for s in (g, o):
+        s.set_keypoints(keys, have_orientation=False)
+    assert g.run(b[None]) == o.run(b[None]) == [len(keys)]
+    _same(g, o, "set_keypoints + run")
+    # more keypoints than the top-K storage would hold
+    g2, o2 = _pair(gpu_ctx_factory, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=50)
+    g2.run(a[None]); o2.run(a[None])
+    many = np.concatenate([keys, keys, keys])
+    assert g2.run_keypoints(many, 1) == o2.run_keypoints(many, 1) == len(many)
+    _same(g2, o2, "list larger than top-K")
+
+
+def test_keypoint_list_errors(gpu_ctx_factory):
+    from hessgpu_amd.session import HessError
+
+    g = gpu_ctx_factory()
+    keys = np.zeros(4, dtype=_abi.KEYPOINT_DTYPE)
+    keys["s"] = 2.0; keys["x"] = 50; keys["y"] = 40
+    with pytest.raises(HessError):
+        g.run_keypoints(keys, 1)  # no current image
+    imgs = np.stack([fixtures.synthetic_blobs(160, 120, i) for i in range(2)])
+    g.set_keypoints(keys, True)
+    with pytest.raises(HessError):
+        g.run(imgs)  # a list applies to one image
+
+
+def test_siftgpu_class_keypoint_list():
+    import siftgpu_lib
+
+    img = fixtures.load_rgb("640-4.jpg")
+    s = siftgpu_lib.SiftGPU([])
+    assert s.run(img, siftgpu_lib.GL_RGB, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    k, d = s.features()
+    L = s.L
+    import ctypes as C
+    L.siftgpu_run_keys.restype = C.c_int
+    L.siftgpu_run_keys.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    assert L.siftgpu_run_keys(s.h, len(k), k.ctypes.data, 1) == 1
+    k2, d2 = s.features()
+    o = OracleSession(threads=8)
+    o.run(img[None])
+    assert o.run_keypoints(k, 1) == len(k)
+    ok, od = o.fetch(0)
+    assert k2.tobytes() == ok.tobytes() and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    s.close()
