@@ -282,7 +282,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
     og.got_off = gt;
     og.row_base = rows;
     og.mask_base = mw;
-    og.tiles_x = (og.wa + 255) / 256;
+    og.tiles_x = (og.wa + 127) / 128;  // EX_TC columns per extrema tile (k_detect.hip)
     og.tile_base = g.ntiles;
     g.ntiles += og.tiles_x * ((og.h + 3) / 4);  // EX_TR rows per extrema tile (k_detect.hip)
     lvl += (long long)c->sch.level_num * B * og.plane;

@@ -245,7 +245,7 @@ __device__ __forceinline__ RowTask decode_row(const Geom& g, int wave, int batch
 //            accepted pixels set their bit in the tile's mask words (LDS atomicOr);
 // then the mask words and per-row counts go to HBM.  Bits are positional, so the list order produced
 // by the scatter pass is independent of the order candidates were queued in.
-constexpr int EX_TR = 4, EX_TC = 256, EX_STRIDE = EX_TC + 8 + 4;  // cols x0-4 .. x0+260, +4 pad
+constexpr int EX_TR = 4, EX_TC = 128, EX_STRIDE = EX_TC + 8 + 4;  // cols x0-4 .. x0+260, +4 pad
 
 __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* deth,
                                                            uint64_t* rowmask, int* rowcnt) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
     // order-dependent test runs in stage 2 on the survivors only. ----
 #pragma unroll 1
     for (int it = 0; it < (EX_TR / 4) * (EX_TC / 64); it++) {
-      const int rl_ = wv * (EX_TR / 4) + (it >> 2), blk = it & 3;
+      const int rl_ = wv * (EX_TR / 4) + it / (EX_TC / 64), blk = it % (EX_TC / 64);
       const int row = y0 + rl_, col = x0 + blk * 64 + lane;
       const int ci = (rl_ + 1) * EX_STRIDE + (blk * 64 + lane + 4);
       const float r = C[ci];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
     __syncthreads();
     // ---- write-out: mask words and row counts of this level ----
     if (threadIdx.x < EX_TR * (EX_TC / 64)) {
-      const int rl_ = threadIdx.x >> 2, blk = threadIdx.x & 3;
+      const int rl_ = threadIdx.x / (EX_TC / 64), blk = threadIdx.x % (EX_TC / 64);
       const int row = y0 + rl_;
       if (row < og.h && x0 + blk * 64 < og.wa) {
         const unsigned long long m = mwords[rl_][blk];
