@@ -577,26 +577,56 @@ void SiftGPU::SaveSIFT(const char* szFileName) {  // SiftPyramid::SaveSIFT, Sift
 }
 
 // ------------------------------------------------------------------------------------------------
-// Matcher / combo classes: declared for source compatibility, not implemented (out of the hot path).
+// SiftMatchGPU on the matcher entry points of the C ABI (reference: SiftMatch.cpp's dispatcher +
+// SiftMatchCU.cpp).  __matcher holds the hess_matcher handle.
 
-static void matcher_notice() {
-  static bool said = false;
-  if (!said) { std::cerr << "SiftMatchGPU is not implemented in this build\n"; said = true; }
-}
+static hess_matcher* MH(SiftMatchGPU* m_as_ptr) { return reinterpret_cast<hess_matcher*>(m_as_ptr); }
+
 SiftMatchGPU::SiftMatchGPU(int max_sift) : __max_sift(max_sift), __language(0), __matcher(nullptr) {}
-SiftMatchGPU::~SiftMatchGPU() {}
-int SiftMatchGPU::_CreateContextGL() { matcher_notice(); return 0; }
-int SiftMatchGPU::_VerifyContextGL() { matcher_notice(); return 0; }
-void SiftMatchGPU::SetLanguage(int language) { __language = language; }
-void SiftMatchGPU::SetDeviceParam(int, char**) {}
-void SiftMatchGPU::SetMaxSift(int max_sift) { __max_sift = max_sift; }
-void SiftMatchGPU::SetDescriptors(int, int, const float*, int) { matcher_notice(); }
-void SiftMatchGPU::SetDescriptors(int, int, const unsigned char*, int) { matcher_notice(); }
-int SiftMatchGPU::GetSiftMatch(int, int[][2], float, float, int) { matcher_notice(); return 0; }
-void SiftMatchGPU::SetFeautreLocation(int, const float*, int) { matcher_notice(); }
-int SiftMatchGPU::GetGuidedSiftMatch(int, int[][2], float[3][3], float[3][3], float, float, float, float, int) {
-  matcher_notice();
-  return 0;
+SiftMatchGPU::~SiftMatchGPU() {
+  if (__matcher) hess_matcher_destroy(MH(__matcher));
+}
+int SiftMatchGPU::_CreateContextGL() { return _VerifyContextGL(); }
+int SiftMatchGPU::_VerifyContextGL() {
+  if (!__matcher) __matcher = reinterpret_cast<SiftMatchGPU*>(hess_matcher_create(__language >= 3 ? __language - 3 : 0, __max_sift));
+  return __matcher ? 1 : 0;
+}
+void SiftMatchGPU::SetLanguage(int language) { __language = language; }  // SIFTMATCH_CUDA_DEVICE0 + i selects device i
+void SiftMatchGPU::SetDeviceParam(int argc, char** argv) {
+  for (int i = 0; i + 1 < argc; i++)
+    if (!strcasecmp(argv[i], "-cuda")) { int d = 0; if (sscanf(argv[i + 1], "%d", &d) == 1 && d >= 0) __language = 3 + d; }
+}
+void SiftMatchGPU::SetMaxSift(int max_sift) {
+  __max_sift = max_sift;
+  if (__matcher) hess_matcher_set_max(MH(__matcher), max_sift);
+}
+void SiftMatchGPU::SetDescriptors(int index, int num, const float* descriptors, int id) {
+  (void)id;
+  if (_VerifyContextGL()) hess_matcher_set_descriptors_f32(MH(__matcher), index, num, descriptors);
+}
+void SiftMatchGPU::SetDescriptors(int index, int num, const unsigned char* descriptors, int id) {
+  (void)id;
+  if (_VerifyContextGL()) hess_matcher_set_descriptors(MH(__matcher), index, num, descriptors);
+}
+int SiftMatchGPU::GetSiftMatch(int max_match, int match_buffer[][2], float distmax, float ratiomax, int mbm) {
+  if (!__matcher) return 0;
+  const int n = hess_matcher_match(MH(__matcher), max_match, &match_buffer[0][0], nullptr, nullptr, distmax, ratiomax, 0, 0, mbm);
+  return n < 0 ? 0 : n;
+}
+void SiftMatchGPU::SetFeautreLocation(int index, const float* locations, int gap) {
+  if (__matcher) hess_matcher_set_locations(MH(__matcher), index, locations, gap);
+}
+int SiftMatchGPU::GetGuidedSiftMatch(int max_match, int match_buffer[][2], float H[3][3], float F[3][3], float distmax,
+                                     float ratiomax, float hdistmax, float fdistmax, int mbm) {
+  if (!__matcher) return 0;
+  // SiftMatchGPU::GetGuidedSiftMatch (SiftMatch.cpp:663-676): no matrix at all -> plain match; a missing
+  // one is replaced by the identity with a distance bound of 1e20
+  if (!H && !F) return GetSiftMatch(max_match, match_buffer, distmax, ratiomax, mbm);
+  static const float Z[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const float ti = 1.0e+20F;
+  const int n = hess_matcher_match(MH(__matcher), max_match, &match_buffer[0][0], H ? &H[0][0] : Z, F ? &F[0][0] : Z,
+                                   distmax, ratiomax, H ? hdistmax : ti, F ? fdistmax : ti, mbm);
+  return n < 0 ? 0 : n;
 }
 void* SiftMatchGPU::operator new(size_t size) {
   void* p = malloc(size);
@@ -615,8 +645,8 @@ void* ComboSiftGPU::operator new(size_t size) {
 extern "C" {
 
 SiftGPU* CreateNewSiftGPU(int np) { return new SiftGPU(np); }
-SiftMatchGPU* CreateNewSiftMatchGPU(int) { matcher_notice(); return nullptr; }
-ComboSiftGPU* CreateComboSiftGPU() { return nullptr; }
+SiftMatchGPU* CreateNewSiftMatchGPU(int max_sift) { return new SiftMatchGPU(max_sift); }
+ComboSiftGPU* CreateComboSiftGPU() { return new ComboSiftGPU(); }
 ComboSiftGPU* CreateRemoteSiftGPU(int, char*) { return nullptr; }
 
 void siftgpu_destroy(SiftGPU* s) { delete s; }
@@ -631,6 +661,16 @@ void siftgpu_save(SiftGPU* s, const char* path) { s->SaveSIFT(path); }
 const float* siftgpu_timing(SiftGPU* s) { return s->_timing; }
 void siftgpu_set_verbose(SiftGPU* s, int v) { s->SetVerbose(v); }
 int siftgpu_image_count(SiftGPU* s) { return s->GetImageCount(); }
+SiftMatchGPU* siftmatch_create(int max_sift) {
+  SiftMatchGPU* m = new SiftMatchGPU(max_sift);
+  m->VerifyContextGL();
+  return m;
+}
+void siftmatch_destroy(SiftMatchGPU* m) { delete m; }
+void siftmatch_set_descriptors_f32(SiftMatchGPU* m, int index, int num, const float* d) { m->SetDescriptors(index, num, d, -1); }
+int siftmatch_get_match(SiftMatchGPU* m, int max_match, int* buf, float distmax, float ratiomax, int mbm) {
+  return m->GetSiftMatch(max_match, reinterpret_cast<int(*)[2]>(buf), distmax, ratiomax, mbm);
+}
 int siftgpu_run_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation) { return s->RunSIFT(num, keys, have_orientation); }
 void siftgpu_set_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation) { s->SetKeypointList(num, keys, have_orientation); }
 

@@ -7,9 +7,8 @@
 // extern "C" factories.  Everything behind it is new: the methods drive the C ABI of
 // include/hess_abi.h (hand-written HIP kernels for gfx950); there is no OpenGL, CUDA or DevIL.
 //
-// Not provided in this build (they return 0 / do nothing and say so on stderr once):
-//   SiftMatchGPU (descriptor matcher), ComboSiftGPU / CreateRemoteSiftGPU (TCP server mode),
-//   SiftGPUEX (viewer), the rectangle-descriptor hack of SetKeypointList (keys_have_orientation == -1).
+// Not provided in this build: CreateRemoteSiftGPU (TCP server mode; returns NULL), SiftGPUEX (viewer),
+// the rectangle-descriptor hack of SetKeypointList (keys_have_orientation == -1).
 #ifndef GPU_SIFT_H
 #define GPU_SIFT_H
 
@@ -119,7 +118,7 @@ class SiftGPU : public SiftParam {
   void* operator new(size_t size);
 };
 
-// Descriptor matcher: declared for source compatibility; not implemented in this build.
+// Descriptor matcher (SiftMatchGPU, CUDA flavour of the reference) on the hess_matcher_* C ABI.
 class SiftMatchGPU {
  public:
   enum SIFTMATCH_LANGUAGE { SIFTMATCH_SAME_AS_SIFTGPU = 0, SIFTMATCH_GLSL = 2, SIFTMATCH_CUDA = 3, SIFTMATCH_CUDA_DEVICE0 = 3 };
@@ -164,8 +163,8 @@ class ComboSiftGPU : public SiftGPU, public SiftMatchGPU {
 };
 
 SIFTGPU_EXPORT_EXTERN SiftGPU* CreateNewSiftGPU(int np = 1);
-SIFTGPU_EXPORT_EXTERN SiftMatchGPU* CreateNewSiftMatchGPU(int max_sift = 4096);  // returns NULL
-SIFTGPU_EXPORT_EXTERN ComboSiftGPU* CreateComboSiftGPU();                         // returns NULL
+SIFTGPU_EXPORT_EXTERN SiftMatchGPU* CreateNewSiftMatchGPU(int max_sift = 4096);
+SIFTGPU_EXPORT_EXTERN ComboSiftGPU* CreateComboSiftGPU();
 SIFTGPU_EXPORT_EXTERN ComboSiftGPU* CreateRemoteSiftGPU(int port = 7777, char* remote_server = NULL);  // NULL
 
 // Flat C mirror of the class for FFI users and tests (ctypes / cgo / JNI cannot call a vtable).
@@ -182,6 +181,10 @@ void siftgpu_save(SiftGPU* s, const char* path);
 const float* siftgpu_timing(SiftGPU* s);
 void siftgpu_set_verbose(SiftGPU* s, int v);
 int siftgpu_image_count(SiftGPU* s);
+SiftMatchGPU* siftmatch_create(int max_sift);
+void siftmatch_destroy(SiftMatchGPU* m);
+void siftmatch_set_descriptors_f32(SiftMatchGPU* m, int index, int num, const float* d);
+int siftmatch_get_match(SiftMatchGPU* m, int max_match, int* buf, float distmax, float ratiomax, int mbm);
 int siftgpu_run_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation);
 void siftgpu_set_keys(SiftGPU* s, int num, const SiftGPU::SiftKeypoint* keys, int have_orientation);
 // The resolved hess_params of the instance (what ParseParam did), for tests.

@@ -188,6 +188,22 @@ int hess_profile_enable(hess_ctx* ctx, int on);
 int hess_profile_get(hess_ctx* ctx, int kernel, double* ms, long long* launches, double* bytes);
 int hess_profile_reset(hess_ctx* ctx);
 
+/* ---- Descriptor matcher: replaces SiftMatchGPU's CUDA flavour, SiftMatchCU
+ * (SiftMatchCU.cpp:71-176) and MultiplyDescriptor(_G)_Kernel / RowMatch_Kernel / ColMatch_Kernel
+ * (ProgramCU.cu:3455-3843).  Descriptors: num x 128 unsigned bytes (512*d rounded); locations: (x,y). */
+typedef struct hess_matcher hess_matcher;
+hess_matcher* hess_matcher_create(int device, int max_sift);          /* SiftMatchGPU(max_sift) */
+void hess_matcher_destroy(hess_matcher* m);
+int hess_matcher_set_max(hess_matcher* m, int max_sift);              /* SetMaxSift */
+int hess_matcher_set_descriptors(hess_matcher* m, int index, int num, const unsigned char* des);
+int hess_matcher_set_descriptors_f32(hess_matcher* m, int index, int num, const float* des);
+int hess_matcher_set_locations(hess_matcher* m, int index, const float* locations, int gap);
+/* GetSiftMatch (H = F = NULL) / GetGuidedSiftMatch; pairs: max_match x 2 ints; returns #matches. */
+int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* H, const float* F,
+                       float distmax, float ratiomax, float hdistmax, float fdistmax, int mutual_best);
+float hess_matcher_last_ms(hess_matcher* m);   /* device time of the last match's kernels */
+const char* hess_matcher_last_error(hess_matcher* m);
+
 /* Test hook: evaluate one of the device's elementary functions (hess_devmath.h) on n inputs.
  * which: 0 exp(a) 1 atan2(a,b) 2 sin(a) 3 cos(a) 4 float->half bits 5 half bits->float 6 a/b 7 sqrt(a). */
 int hess_math_probe(hess_ctx* ctx, int which, const float* a, const float* b, float* out, int n);

@@ -1260,3 +1260,126 @@ float hess_cpu_atan2f(float y, float x) { return om_atan2f(y, x); }
 void hess_cpu_sincosf(float a, float* s, float* c) { om_sincosf(a, s, c); }
 unsigned short hess_cpu_f2h(float f) { return om_f2h(f); }
 float hess_cpu_h2f(unsigned short h) { return om_h2f(h); }
+
+/* ========================================================================================== */
+/* Descriptor matcher: restatement of MultiplyDescriptor(_G)_Kernel,
+ * RowMatch_Kernel, ColMatch_Kernel (ProgramCU.cu:3455-3843) and SiftMatchCU::GetBestMatch
+ * (SiftMatchCU.cpp:148-173).  Descriptors are u8 (512*d rounded, SiftMatchCU.cpp:94-99). */
+
+void hess_cpu_match_quantize(const float* desc, int count, unsigned char* out) {
+  for (int i = 0; i < count; ++i) out[i] = (unsigned char)(int)(512 * desc[i] + 0.5); /* SiftMatchCU.cpp:97 */
+}
+
+int hess_cpu_match(const unsigned char* des1, int num1, const unsigned char* des2, int num2, const float* loc1,
+                   const float* loc2, const float* H, const float* F, float distmax, float ratiomax,
+                   float hdistmax, float fdistmax, int mutual_best, int max_match, int* pairs) {
+  if (!des1 || !des2 || num1 <= 0 || num2 <= 0 || !pairs) return 0;
+  const int guided = (loc1 && loc2 && H && F);
+  int* dot = (int*)malloc((size_t)num1 * num2 * sizeof(int));   /* d_result */
+  int* raw = (int*)malloc((size_t)num1 * num2 * sizeof(int));   /* `results` before the clamp */
+  int* rowm = (int*)malloc((size_t)num1 * sizeof(int));
+  int* colm = (int*)malloc((size_t)num2 * sizeof(int));
+  if (!dot || !raw || !rowm || !colm) return 0;
+#pragma omp parallel for schedule(static)
+  for (int blk = 0; blk < (num1 + 7) / 8; blk++) { /* MULT_BLOCK_DIMY = 8 rows per block */
+    for (int j = 0; j < num2; j++) {
+      int res[8], good = 0, rows = 0;
+      for (int k = 0; k < 8; k++) {
+        int i = blk * 8 + k;
+        res[k] = 0;
+        if (guided) { /* ProgramCU.cu:3597-3635 */
+          if (i < num1) {
+            float locx = loc1[2 * i], locy = loc1[2 * i + 1], l2x = loc2[2 * j], l2y = loc2[2 * j + 1];
+            float x0 = fmaf(H[0], locx, H[1] * locy) + H[2];
+            float x1 = fmaf(H[3], locx, H[4] * locy) + H[5];
+            float x2 = fmaf(H[6], locx, H[7] * locy) + H[8];
+            float d0 = fabsf(x0 / x2 - l2x), d1 = fabsf(x1 / x2 - l2y);
+            if (d0 < hdistmax && d1 < hdistmax) {
+              float fx0 = fmaf(F[0], locx, F[1] * locy) + F[2];
+              float fx1 = fmaf(F[3], locx, F[4] * locy) + F[5];
+              float fx2 = fmaf(F[6], locx, F[7] * locy) + F[8];
+              float ft0 = fmaf(F[0], l2x, F[3] * l2y) + F[6];
+              float ft1 = fmaf(F[1], l2x, F[4] * l2y) + F[7];
+              float x2fx1 = fmaf(l2x, fx0, l2y * fx1) + fx2;
+              float se = (x2fx1 * x2fx1) / fmaf(ft1, ft1, fmaf(ft0, ft0, fmaf(fx0, fx0, fx1 * fx1)));
+              res[k] = se < fdistmax ? 0 : -262144;
+            } else res[k] = -262144;
+          } else res[k] = -262144;
+          good += (res[k] >= 0);
+        }
+        if (i < num1) rows++;
+      }
+      if (!guided || good > 0) {
+        for (int k = 0; k < 8; k++) {
+          int i = blk * 8 + k;
+          if (i >= num1) continue; /* rows past the end read unspecified texels in the reference; never stored */
+          const unsigned char *p1 = des1 + (size_t)i * 128, *p2 = des2 + (size_t)j * 128;
+          int acc = 0;
+          for (int t = 0; t < 128; t++) acc += (int)p1[t] * (int)p2[t];
+          res[k] += acc;
+        }
+      }
+      for (int k = 0; k < rows; k++) {
+        int i = blk * 8 + k;
+        raw[(size_t)i * num2 + j] = res[k];
+        dot[(size_t)i * num2 + j] = guided ? (res[k] > 0 ? res[k] : 0) : res[k]; /* :3684 max(results,0) */
+      }
+    }
+  }
+  /* RowMatch_Kernel, ProgramCU.cu:3737-3791: 32 threads stride the row, strict '>' keeps the first
+   * maximum per thread, the tree keeps the lower thread on ties; second best = second largest value. */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < num1; i++) {
+    int tmax[32], tnxt[32], tidx[32];
+    for (int t = 0; t < 32; t++) { tmax[t] = 0; tnxt[t] = 0; tidx[t] = -1; }
+    for (int j = 0; j < num2; j++) {
+      int t = j & 31, v = dot[(size_t)i * num2 + j];
+      int test = v > tmax[t];
+      tnxt[t] = test ? tmax[t] : (tnxt[t] > v ? tnxt[t] : v);
+      tidx[t] = test ? j : tidx[t];
+      tmax[t] = test ? v : tmax[t];
+    }
+    for (int step = 16; step > 0; step /= 2)
+      for (int t = 0; t < step; t++) {
+        int v1 = tmax[t], v2 = tmax[t + step];
+        int test = v2 > v1;
+        tnxt[t] = test ? (v1 > tnxt[t + step] ? v1 : tnxt[t + step]) : (tnxt[t] > v2 ? tnxt[t] : v2);
+        tidx[t] = test ? tidx[t + step] : tidx[t];
+        tmax[t] = test ? v2 : v1;
+      }
+    float dist = (float)acos(fmin((double)(tmax[0] * 0.000003814697265625f), 1.0));
+    float distn = (float)acos(fmin((double)(tnxt[0] * 0.000003814697265625f), 1.0));
+    rowm[i] = (dist < distmax) && (dist < distn * ratiomax) ? tidx[0] : -1;
+  }
+  if (mutual_best) { /* per 8-row block (max, index, second) on the unclamped results, then ColMatch_Kernel */
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < num2; j++) {
+      int rx = 0, ry = -1, rz = 0, first = 1;
+      for (int blk = 0; blk < (num1 + 7) / 8; blk++) {
+        int cx = 0, cy = -1, cz = 0;
+        for (int k = 0; k < 8 && blk * 8 + k < num1; k++) {
+          int v = raw[(size_t)(blk * 8 + k) * num2 + j];
+          if (v > cx) { cz = cx; cx = v; cy = blk * 8 + k; }
+          else cz = cz > v ? cz : v;
+        }
+        if (first) { rx = cx; ry = cy; rz = cz; first = 0; }
+        else if (rx < cx) { rz = rx > cz ? rx : cz; rx = cx; ry = cy; }
+        else rz = rz > cx ? rz : cx;
+      }
+      float dist = (float)acos(fmin((double)(rx * 0.000003814697265625f), 1.0));
+      float distn = (float)acos(fmin((double)(rz * 0.000003814697265625f), 1.0));
+      colm[j] = (dist < distmax) && (dist < distn * ratiomax) ? ry : -1;
+    }
+  }
+  int nmatch = 0; /* SiftMatchCU.cpp:161-171 */
+  for (int i = 0; i < num1 && nmatch < max_match; ++i) {
+    int j = rowm[i];
+    if (j >= 0 && (!mutual_best || colm[j] == i)) {
+      pairs[2 * nmatch] = i;
+      pairs[2 * nmatch + 1] = j;
+      nmatch++;
+    }
+  }
+  free(dot); free(raw); free(rowm); free(colm);
+  return nmatch;
+}

@@ -52,6 +52,14 @@ const char* hess_cpu_last_error(hess_cpu_ctx* ctx);
 int hess_cpu_filter_taps(hess_cpu_ctx* ctx, int level, float* taps);
 float hess_cpu_level_sigma(hess_cpu_ctx* ctx, int level);
 
+/* Descriptor matcher (SiftMatchGPU, CUDA flavour: SiftMatchCU.cpp:71-176, ProgramCU.cu:3455-3843).
+ * des: num x 128 unsigned bytes; loc: num x (x,y) floats; H, F: 3x3 row-major, all four NULL for the
+ * unguided match; pairs: max_match x 2 ints.  Returns the number of matches. */
+void hess_cpu_match_quantize(const float* desc, int count, unsigned char* out);
+int hess_cpu_match(const unsigned char* des1, int num1, const unsigned char* des2, int num2, const float* loc1,
+                   const float* loc2, const float* H, const float* F, float distmax, float ratiomax,
+                   float hdistmax, float fdistmax, int mutual_best, int max_match, int* pairs);
+
 /* Elementary-function probes for tests/test_oracle_math.py. */
 float hess_cpu_expf(float x);
 float hess_cpu_atan2f(float y, float x);

@@ -64,3 +64,33 @@ class OracleSession(Session):
 
     def level_sigma(self, level):
         return lib().hess_cpu_level_sigma(self._h, level)
+
+
+def oracle_quantize(desc):
+    """float descriptors -> u8 as SiftMatchCU::SetDescriptors does (int(512*d + 0.5))."""
+    import numpy as np
+
+    L = lib()
+    d = np.ascontiguousarray(desc, dtype=np.float32)
+    out = np.zeros(d.shape, dtype=np.uint8)
+    L.hess_cpu_match_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.hess_cpu_match_quantize(d.ctypes.data, d.size, out.ctypes.data)
+    return out
+
+
+def oracle_match(des1, des2, loc1=None, loc2=None, H=None, F=None, distmax=0.7, ratiomax=0.8, hdistmax=32.0,
+                 fdistmax=16.0, mutual_best=True, max_match=4096):
+    """CPU oracle of the matcher (oracle/hess_oracle.c: hess_cpu_match); u8 descriptors [n,128]."""
+    import numpy as np
+
+    L = lib()
+    L.hess_cpu_match.restype = C.c_int
+    L.hess_cpu_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    d1, d2 = np.ascontiguousarray(des1, np.uint8), np.ascontiguousarray(des2, np.uint8)
+    arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (loc1, loc2, H, F)]
+    ptr = [None if a is None else a.ctypes.data for a in arrs]
+    out = np.zeros((max(max_match, 1), 2), dtype=np.int32)
+    n = L.hess_cpu_match(d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), ptr[0], ptr[1], ptr[2], ptr[3], distmax,
+                         ratiomax, hdistmax, fdistmax, int(mutual_best), max_match, out.ctypes.data)
+    return out[:n].copy()

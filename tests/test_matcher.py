@@ -1,0 +1,140 @@
+"""Descriptor matcher.  CPU: the oracle against an independent NumPy brute force
+(integer dot products, the reference's tie order).  GPU: the HIP matcher (hess_matcher_*, and the
+SiftMatchGPU class) against the oracle -- integer work, bit-exact."""
+import numpy as np
+import pytest
+
+import fixtures
+from oracle_lib import OracleSession, oracle_match, oracle_quantize
+
+
+def _descs():
+    o = OracleSession(threads=4, keep_levels=False)
+    out = []
+    for name in ("640-1.jpg", "640-2.jpg"):
+        o.run(fixtures.load_rgb(name)[None])
+        k, d = o.fetch(0)
+        out.append((k, d))
+    return out
+
+
+def _numpy_match(d1, d2, distmax=0.7, ratiomax=0.8, mutual=True, max_match=4096):
+    dot = d1.astype(np.int64) @ d2.astype(np.int64).T
+    n1, n2 = dot.shape
+
+    def decide(best, second, idx):
+        dist = np.float32(np.arccos(min(float(np.float32(best) * np.float32(0.000003814697265625)), 1.0)))
+        distn = np.float32(np.arccos(min(float(np.float32(second) * np.float32(0.000003814697265625)), 1.0)))
+        return idx if (dist < np.float32(distmax) and dist < distn * np.float32(ratiomax)) else -1
+
+    rowm = []
+    for i in range(n1):
+        v = dot[i]
+        best = max(int(v.max()), 0)
+        cand = np.flatnonzero(v == best) if best > 0 else np.array([], int)
+        # RowMatch_Kernel's tree (partner 16, 8, 4, 2, 1 away, ties keep the lower thread) resolves equal
+        # maxima towards the smallest BIT-REVERSED class j%32, then the lowest j inside the class
+        brev = lambda c: int(format(c, "05b")[::-1], 2)
+        idx = int(min(cand, key=lambda j: (brev(j % 32), j))) if len(cand) else -1
+        vals = np.sort(np.concatenate([v, [0, 0]]))[::-1]
+        rowm.append(decide(best, int(vals[1]), idx))
+    colm = []
+    for j in range(n2):
+        v = dot[:, j]
+        best = max(int(v.max()), 0)
+        idx = int(np.flatnonzero(v == best)[0]) if best > 0 else -1            # lowest row
+        vals = np.sort(np.concatenate([v, [0, 0]]))[::-1]
+        colm.append(decide(best, int(vals[1]), idx))
+    out = []
+    for i in range(n1):
+        j = rowm[i]
+        if j >= 0 and (not mutual or colm[j] == i) and len(out) < max_match:
+            out.append((i, j))
+    return np.array(out, dtype=np.int32).reshape(-1, 2)
+
+
+def test_oracle_matcher_vs_numpy_bruteforce():
+    (k1, f1), (k2, f2) = _descs()
+    q1, q2 = oracle_quantize(f1), oracle_quantize(f2)
+    assert np.array_equal(q1, np.floor(512.0 * f1.astype(np.float64) + 0.5).astype(np.int64).astype(np.uint8))
+    for mutual in (True, False):
+        a = oracle_match(q1, q2, mutual_best=mutual)
+        b = _numpy_match(q1, q2, mutual=mutual)
+        assert np.array_equal(a, b) and len(a) > 0
+    # an image matched with itself: every feature finds itself unless a duplicate descriptor blocks the ratio test
+    s = oracle_match(q1, q1)
+    assert (s[:, 0] == s[:, 1]).all() and len(s) > 0.5 * len(q1)
+    # ties: duplicated descriptors resolve by the row kernel's tree order on rows and lowest i on columns
+    rng = np.random.RandomState(0)
+    r1 = (rng.rand(70, 128) * 60).astype(np.uint8)
+    r2 = np.concatenate([r1[::-1], r1[:40]])
+    for mutual in (True, False):
+        assert np.array_equal(oracle_match(r1, r2, ratiomax=2.0, distmax=2.0, mutual_best=mutual),
+                              _numpy_match(r1, r2, ratiomax=2.0, distmax=2.0, mutual=mutual))
+    assert len(oracle_match(q1, q1, max_match=3)) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_matcher_bit_exact_vs_oracle():
+    from hessgpu_amd.matcher import Matcher
+
+    (k1, f1), (k2, f2) = _descs()
+    q1, q2 = oracle_quantize(f1), oracle_quantize(f2)
+    m = Matcher(0, max_sift=8192)
+    m.set_descriptors(0, f1)   # float path quantises on the host like the reference
+    m.set_descriptors(1, q2)   # byte path
+    for mutual in (True, False):
+        for dm, rm in ((0.7, 0.8), (1.2, 0.95), (2.0, 2.0)):
+            a = m.match(distmax=dm, ratiomax=rm, mutual_best=mutual)
+            b = oracle_match(q1, q2, distmax=dm, ratiomax=rm, mutual_best=mutual)
+            assert np.array_equal(a, b), (mutual, dm, rm)
+    assert len(m.match(max_match=2)) == 2
+    # guided: identity homography with a loose bound, then a tight one; a random fundamental matrix
+    l1 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    l2 = np.stack([k2["x"], k2["y"]], 1).astype(np.float32)
+    m.set_locations(0, np.concatenate([l1, np.zeros((len(l1), 3), np.float32)], 1), gap=3)
+    m.set_locations(1, l2)
+    H = np.eye(3, dtype=np.float32)
+    F = np.array([[0, -1e-3, 0.2], [1e-3, 0, -0.3], [-0.2, 0.3, 0]], np.float32)
+    for hd, fd in ((1e20, 1e20), (80.0, 1e20), (200.0, 5.0), (0.5, 0.1)):
+        for mutual in (True, False):
+            a = m.match(H=H, F=F, hdistmax=hd, fdistmax=fd, mutual_best=mutual, distmax=1.5, ratiomax=1.5)
+            b = oracle_match(q1, q2, l1, l2, H, F, hdistmax=hd, fdistmax=fd, mutual_best=mutual, distmax=1.5, ratiomax=1.5)
+            assert np.array_equal(a, b), (hd, fd, mutual)
+    # ragged sizes, ties, max_sift clamp
+    rng = np.random.RandomState(1)
+    r1 = (rng.rand(1000, 128) * 50).astype(np.uint8)
+    r2 = np.concatenate([r1[::-1][:300], (rng.rand(477, 128) * 50).astype(np.uint8), r1[:100]])
+    m.set_descriptors(0, r1)
+    m.set_descriptors(1, r2)
+    for mutual in (True, False):
+        assert np.array_equal(m.match(mutual_best=mutual, ratiomax=2.0, distmax=2.0),
+                              oracle_match(r1, r2, mutual_best=mutual, ratiomax=2.0, distmax=2.0))
+    small = Matcher(0, max_sift=64)
+    small.set_descriptors(0, r1)
+    small.set_descriptors(1, r2)
+    assert np.array_equal(small.match(ratiomax=2.0, distmax=2.0), oracle_match(r1[:64], r2[:64], ratiomax=2.0, distmax=2.0))
+    m.close()
+    small.close()
+
+
+@pytest.mark.gpu
+def test_siftmatchgpu_class_through_the_c_mirror():
+    import ctypes as C
+
+    import siftgpu_lib
+
+    L = siftgpu_lib.lib()
+    for name, res, args in [("siftmatch_create", C.c_void_p, [C.c_int]), ("siftmatch_destroy", None, [C.c_void_p]),
+                            ("siftmatch_set_descriptors_f32", None, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                            ("siftmatch_get_match", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int])]:
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    (k1, f1), (k2, f2) = _descs()
+    h = L.siftmatch_create(4096)
+    L.siftmatch_set_descriptors_f32(h, 0, len(f1), f1.ctypes.data)
+    L.siftmatch_set_descriptors_f32(h, 1, len(f2), f2.ctypes.data)
+    buf = np.zeros((4096, 2), np.int32)
+    n = L.siftmatch_get_match(h, 4096, buf.ctypes.data, 0.7, 0.8, 1)
+    assert np.array_equal(buf[:n], oracle_match(oracle_quantize(f1), oracle_quantize(f2)))
+    L.siftmatch_destroy(h)
