@@ -19,7 +19,9 @@ def test_factories_exist_and_unsupported_ones_return_null():
     L = siftgpu_lib.lib()
     for name in ("CreateNewSiftGPU", "CreateNewSiftMatchGPU", "CreateComboSiftGPU", "CreateRemoteSiftGPU"):
         assert hasattr(L, name)
-    assert L.CreateComboSiftGPU() is None
+    L.CreateRemoteSiftGPU.argtypes = [C.c_int, C.c_char_p]
+    assert L.CreateRemoteSiftGPU(7777, None) is None  # TCP server mode is out of scope
+    assert L.CreateComboSiftGPU() is not None and L.CreateNewSiftMatchGPU(4096) is not None
 
 
 def test_defaults_resolve_like_ParseSiftParam():
