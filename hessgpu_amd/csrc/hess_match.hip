@@ -11,7 +11,8 @@
 //   match_row_kernel   one wavefront per row: best / second best with the reference's tie order (its
 //                      32-thread tree: partners 16, 8, 4, 2, 1 apart, ties keep the lower thread), acos
 //                      distance + ratio test;
-//   match_col_kernel   one thread per column, rows in ascending order (coalesced across threads).
+//   match_col_kernel   one thread per column merges the per-tile (max, index, second) partials that the
+//                      dot kernel's epilogue produced, in ascending row order.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -33,13 +34,16 @@ struct GeoParams {
   float hdistmax, fdistmax;
 };
 
-// raw[i][j]  = the reference's `results` (geometry offset + dot) ; dotm[i][j] = what RowMatch reads.
+// dotm[i][j] = what RowMatch reads (clamped at 0 in guided mode).  cpart[tile_row][j] = (max, index,
+// second) of the reference's unclamped `results` over the tile's 64 rows in ascending order -- the
+// d_temp partials of MultiplyDescriptor_Kernel (ProgramCU.cu:3510-3524), 64 rows at a time instead of 8.
 __global__ __launch_bounds__(256) void match_dot_kernel(const uint8_t* des1, int num1, const uint8_t* des2, int num2,
                                                         const float2* loc1, const float2* loc2, GeoParams gp,
-                                                        int* raw, int* dotm) {
+                                                        int3* cpart, int* dotm) {
   __shared__ uint32_t a[TM][KD / 4 + 1];  // +1 dword: conflict-free column-of-rows reads
   __shared__ uint32_t b[TN][KD / 4 + 1];
   __shared__ int good_blk[TM / 8][TN];
+  __shared__ int3 cp[TM / 4][TN];
   const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN, tid = threadIdx.x;
   for (int g = tid; g < TM * (KD / 16); g += 256) {  // 16-byte loads
     const int r = g >> 3, q = g & 7;
@@ -102,6 +106,9 @@ __global__ __launch_bounds__(256) void match_dot_kernel(const uint8_t* des1, int
     }
   }
   __syncthreads();
+  int3 loc_c[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) loc_c[c] = make_int3(0, -1, 0);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int i = i0 + ti + r;
@@ -112,8 +119,25 @@ __global__ __launch_bounds__(256) void match_dot_kernel(const uint8_t* des1, int
       if (j >= num2) continue;
       int res = acc[r][c];
       if (gp.guided) res = base[r][c] + (good_blk[(ti + r) >> 3][tj + c] > 0 ? acc[r][c] : 0);
-      raw[(size_t)i * num2 + j] = res;
       dotm[(size_t)i * num2 + j] = gp.guided ? max(res, 0) : res;  // ProgramCU.cu:3684
+      if (cpart) {  // strict '>' in ascending row order: the lowest row keeps a tie (ProgramCU.cu:3516-3519)
+        if (res > loc_c[c].x) loc_c[c] = make_int3(res, i, loc_c[c].x);
+        else loc_c[c].z = max(loc_c[c].z, res);
+      }
+    }
+  }
+  if (cpart) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) cp[tid >> 4][tj + c] = loc_c[c];
+    __syncthreads();
+    if (tid < TN && j0 + tid < num2) {
+      int3 t = cp[0][tid];
+      for (int q = 1; q < TM / 4; q++) {  // merge the 16 four-row partials in row order (ColMatch_Kernel's rule)
+        const int3 u = cp[q][tid];
+        if (t.x < u.x) t = make_int3(u.x, u.y, max(t.x, u.z));
+        else t.z = max(t.z, u.x);
+      }
+      cpart[(size_t)blockIdx.y * num2 + j0 + tid] = t;
     }
   }
 }
@@ -156,18 +180,18 @@ __global__ __launch_bounds__(256) void match_row_kernel(const int* dotm, int num
   if (lane == 0) rowm[row] = decide(mx, nx, ix, distmax, ratiomax);
 }
 
-// Column match: (max, index, second) over the unclamped results, rows ascending, strict '>'.
-__global__ __launch_bounds__(256) void match_col_kernel(const int* raw, int num1, int num2, float distmax,
+// ColMatch_Kernel (ProgramCU.cu:3808-3827): merge the row-tile partials of a column in ascending order.
+__global__ __launch_bounds__(256) void match_col_kernel(const int3* cpart, int ntile, int num2, float distmax,
                                                         float ratiomax, int* colm) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= num2) return;
-  int mx = 0, nx = 0, ix = -1;
-  for (int i = 0; i < num1; i++) {
-    const int v = raw[(size_t)i * num2 + j];
-    if (v > mx) { nx = mx; mx = v; ix = i; }
-    else nx = max(nx, v);
+  int3 t = cpart[j];
+  for (int q = 1; q < ntile; q++) {
+    const int3 u = cpart[(size_t)q * num2 + j];
+    if (t.x < u.x) t = make_int3(u.x, u.y, max(t.x, u.z));
+    else t.z = max(t.z, u.x);
   }
-  colm[j] = decide(mx, nx, ix, distmax, ratiomax);
+  colm[j] = decide(t.x, t.z, t.y, distmax, ratiomax);
 }
 
 }  // namespace
@@ -178,7 +202,8 @@ struct hess_matcher {
   uint8_t* des[2] = {nullptr, nullptr};
   float2* loc[2] = {nullptr, nullptr};
   int num[2] = {0, 0}, have_loc[2] = {0, 0};
-  int *raw = nullptr, *dotm = nullptr, *rowm = nullptr, *colm = nullptr;
+  int3* cpart = nullptr;
+  int *dotm = nullptr, *rowm = nullptr, *colm = nullptr;
   size_t mat_cap = 0;
   std::vector<int> hrow, hcol;
   std::string err;
@@ -220,7 +245,7 @@ void hess_matcher_destroy(hess_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   for (int k = 0; k < 2; k++) { (void)hipFree(m->des[k]); (void)hipFree(m->loc[k]); }
-  (void)hipFree(m->raw); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
+  (void)hipFree(m->cpart); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
   if (m->e0) (void)hipEventDestroy(m->e0);
   if (m->e1) (void)hipEventDestroy(m->e1);
   if (m->st) (void)hipStreamDestroy(m->st);
@@ -288,9 +313,10 @@ int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* 
   M_TRY(m, hipSetDevice(m->device));
   const size_t need = (size_t)n1 * n2;
   if (need > m->mat_cap) {
-    (void)hipFree(m->raw); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
-    m->raw = m->dotm = m->rowm = m->colm = nullptr;
-    M_TRY(m, hipMalloc(&m->raw, need * sizeof(int)));
+    (void)hipFree(m->cpart); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
+    m->cpart = nullptr;
+    m->dotm = m->rowm = m->colm = nullptr;
+    M_TRY(m, hipMalloc(&m->cpart, (size_t)((m->max_sift + TM - 1) / TM + 1) * m->max_sift * sizeof(int3)));
     M_TRY(m, hipMalloc(&m->dotm, need * sizeof(int)));
     M_TRY(m, hipMalloc(&m->rowm, (size_t)m->max_sift * sizeof(int) + 4));
     M_TRY(m, hipMalloc(&m->colm, (size_t)m->max_sift * sizeof(int) + 4));
@@ -302,12 +328,12 @@ int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* 
   if (guided) { memcpy(gp.H, H, 36); memcpy(gp.F, F, 36); gp.hdistmax = hdistmax; gp.fdistmax = fdistmax; }
   (void)hipEventRecord(m->e0, m->st);
   hipLaunchKernelGGL(match_dot_kernel, dim3((n2 + TN - 1) / TN, (n1 + TM - 1) / TM), dim3(256), 0, m->st, m->des[0], n1,
-                     m->des[1], n2, m->loc[0], m->loc[1], gp, m->raw, m->dotm);
+                     m->des[1], n2, m->loc[0], m->loc[1], gp, mutual_best ? m->cpart : nullptr, m->dotm);
   hipLaunchKernelGGL(match_row_kernel, dim3((n1 + 3) / 4), dim3(256), 0, m->st, m->dotm, n1, n2, distmax, ratiomax,
                      m->rowm);
   if (mutual_best)
-    hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 255) / 256), dim3(256), 0, m->st, m->raw, n1, n2, distmax, ratiomax,
-                       m->colm);
+    hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 255) / 256), dim3(256), 0, m->st, m->cpart, (n1 + TM - 1) / TM, n2,
+                       distmax, ratiomax, m->colm);
   (void)hipEventRecord(m->e1, m->st);
   m->hrow.resize(n1);
   m->hcol.resize(n2);

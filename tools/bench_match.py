@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Throughput of the descriptor matcher (hess_matcher_*) on the GPU, with the CPU
+oracle timed beside it on a smaller problem.  Prints one JSON line per size."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from hessgpu_amd.matcher import Matcher
+
+
+def main():
+    rng = np.random.RandomState(0)
+    for n in (1024, 4096, 8192):
+        d1 = (rng.rand(n, 128) * 45).astype(np.uint8)
+        d2 = (rng.rand(n, 128) * 45).astype(np.uint8)
+        m = Matcher(0, max_sift=n)
+        m.set_descriptors(0, d1)
+        m.set_descriptors(1, d2)
+        m.match(max_match=n)
+        ts = []
+        for _ in range(10):
+            m.match(max_match=n)
+            ts.append(m.last_ms())
+        ms = float(np.median(ts))
+        traffic = n * n * 4 * 2  # score matrix written once, read once by the row pass (column partials are small)
+        out = {"n1": n, "n2": n, "device_ms": round(ms, 4), "GMAC_per_s": round(n * n * 128 / ms / 1e6, 1),
+               "algorithmic_GB_per_s": round(traffic / ms / 1e6, 1), "bound": "hbm (int32 score matrix)"}
+        if n == 1024:
+            from oracle_lib import oracle_match
+
+            t0 = time.perf_counter()
+            oracle_match(d1, d2, max_match=n)
+            out["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        print(json.dumps(out), flush=True)
+        m.close()
+
+
+if __name__ == "__main__":
+    main()
