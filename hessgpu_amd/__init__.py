@@ -13,7 +13,7 @@ from . import _abi
 from .session import HessError, Session, make_params
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_HERE, "libhessgpu.so")
+LIB_PATH = _os.environ.get("HESS_LIB") or _os.path.join(_HERE, "libhessgpu.so")  # HESS_LIB: developer override
 _lib = None
 _fns = None
 

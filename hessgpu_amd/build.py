@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-            "-Wno-unused-function", f"--offload-arch={ARCH}"]
+            "-Wno-unused-function", f"--offload-arch={ARCH}"] + os.environ.get("HESS_EXTRA_FLAGS", "").split()
 
 KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_pipeline.hip", "hess_match.hip"]
 
