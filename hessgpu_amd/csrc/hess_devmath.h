@@ -17,8 +17,10 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 // e^x, x in [-87, 88]; 0 below (weights there are < 1.7e-38).
 __device__ __forceinline__ float dm_expf(float x) {
-  if (x < -87.0f) return 0.0f;
-  if (x > 88.0f) x = 88.0f;
+  // branch-free form of `if (x < -87) return 0; if (x > 88) x = 88;`
+  const bool under = x < -87.0f;
+  x = (x > 88.0f) ? 88.0f : x;
+  x = under ? -87.0f : x;  // keeps the exponent arithmetic in range; the result is discarded
   float n = rintf(x * 1.44269504088896341f);
   float r = fmaf(n, -0.693359375f, x);
   r = fmaf(n, 2.12194440e-4f, r);
@@ -32,7 +34,8 @@ __device__ __forceinline__ float dm_expf(float x) {
   p = fmaf(p, z, r);
   p = p + 1.0f;
   int e = (int)n + 127;
-  return p * u2f((uint32_t)e << 23);
+  const float v = p * u2f((uint32_t)e << 23);
+  return under ? 0.0f : v;
 }
 
 // a^e from ln(a): the orientation kernel's pow(sigma_step, ds) (ProgramCU.cu:1297).

@@ -282,6 +282,21 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 
 // ================================= descriptor ================================================
 
+constexpr int DL_CAP = 64;     // records a cell's list holds between two drains
+constexpr int DL_STRIDE = 66;  // list pitch in records: 132 dwords = 4 (mod 64) -> the 16 lists of a
+                               // wavefront start in different LDS banks (conflict-free b128 reads)
+
+// One wavefront per feature.  Lane = cell*4 + q.
+//   phase 1  the four lanes of a cell take four consecutive samples of the cell's box per iteration
+//            (scan order of ProgramCU.cu:1723-1774: y outer, x inner), so the 16 cells advance together
+//            with no cross-lane broadcast; hits are appended, in scan order, to the cell's list in LDS;
+//   phase 2  ("drain") lane (cell, q) owns the accumulators des[q], des[q+4] (q = 0 also des[8]) of
+//            its cell and walks the list in order: one fmaf per record and bin, exactly the reference's
+//            `des[fidx] += w1*weight; des[fidx+1] += w2*weight` sequence for every bin.
+// The coefficient of bin j for a record is written as med3(0, (j+1)-theta, theta-(j-1)): for
+// floor(theta) == j that is w1 = fo+1-theta, for floor(theta) == j-1 it is w2 = theta-fo (same single
+// subtraction as the reference), otherwise 0 -- and fmaf(0, weight, acc) == acc because weights and
+// accumulators are non-negative and finite.
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
                                                          int cap_list, const FRec* recs,
                                                          const int* fsrc, const int* feat_total,
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
                                                          const float* got, HostKeypoint* keys, float* desc,
                                                          int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
-  __shared__ float2 rec_lds[4][16][64];  // per wavefront: one round's (theta, weight) records per cell
+  __shared__ __attribute__((aligned(16))) float2 rec_lds[4][16 * DL_STRIDE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int ftotal = feat_total[b], ffirst = feat_first[b];
@@ -297,6 +312,16 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const int nwaves = gridDim.x * 4;
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;
+  const int mycell = lane >> 2, sub = lane & 3;
+  float2* const rlist = &rec_lds[wv][0];
+  float2* const mylist = rlist + mycell * DL_STRIDE;
+  // stale list entries are read (with weight forced to 0) when lists have different lengths: make
+  // sure they are finite from the start
+  for (int i = lane; i < 16 * DL_STRIDE; i += 64) rlist[i] = make_float2(0.0f, 0.0f);
+  // bin constants of this lane: des[sub] and des[sub+4]; des[8] only gets w2 of floor(theta) == 7
+  const float jlo1 = (float)(sub + 1), jlom = (float)(sub - 1);
+  const float jhi1 = (float)(sub + 5), jhim = (float)(sub + 3);
+  const float j8m = (sub == 0) ? 7.0f : 1.0e6f;
 
   for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
     const int src = fsrc[(long long)b * cap_feat + m];
@@ -340,112 +365,87 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     const float crspt = c / spt, srspt = s / spt;
     const float bsz = fabsf(cspt) + fabsf(sspt);
 
-    // Cell geometry (ProgramCU.cu:1692-1716): lane c < 16 holds the constants of cell c.
-    const int cc_ = lane & 15;
-    const float offx_l = (cc_ & 3) - 1.5f, offy_l = (cc_ >> 2) - 1.5f;
-    const float ptx_l = fmaf(cspt, offx_l, -(sspt * offy_l)) + kx;
-    const float pty_l = fmaf(cspt, offy_l, sspt * offx_l) + ky;
-    const float xmin_l = fmaxf(1.5f, floorf(ptx_l - bsz) + 0.5f);
-    const float ymin_l = fmaxf(1.5f, floorf(pty_l - bsz) + 0.5f);
-    const float xmax_l = fminf(width - 1.5f, floorf(ptx_l + bsz) + 0.5f);
-    const float ymax_l = fminf(height - 1.5f, floorf(pty_l + bsz) + 0.5f);
-    const int nxs_l = (xmax_l >= xmin_l) ? (int)(xmax_l - xmin_l) + 1 : 0;
-    const int nys_l = (ymax_l >= ymin_l) ? (int)(ymax_l - ymin_l) + 1 : 0;
-    const int total_l = nxs_l * nys_l;
-    const float inv_l = 1.0f / (float)(nxs_l > 0 ? nxs_l : 1);
-    int maxtotal = total_l;
+    // Cell geometry (ProgramCU.cu:1692-1716), every lane for its own cell.
+    const float offx = (mycell & 3) - 1.5f, offy = (mycell >> 2) - 1.5f;
+    const float ptx = fmaf(cspt, offx, -(sspt * offy)) + kx;
+    const float pty = fmaf(cspt, offy, sspt * offx) + ky;
+    const float xmin = fmaxf(1.5f, floorf(ptx - bsz) + 0.5f);
+    const float ymin = fmaxf(1.5f, floorf(pty - bsz) + 0.5f);
+    const float xmax = fminf(width - 1.5f, floorf(ptx + bsz) + 0.5f);
+    const float ymax = fminf(height - 1.5f, floorf(pty + bsz) + 0.5f);
+    const int nxs = (xmax >= xmin) ? (int)(xmax - xmin) + 1 : 0;
+    const int nys = (ymax >= ymin) ? (int)(ymax - ymin) + 1 : 0;
+    const int total = nxs * nys;
+    const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
+    // sample (sx, sy) of the box is pixel (xmin+sx, ymin+sy): (int)y * width + (int)x = base + sy*width + sx
+    const int base = (int)ymin * width + (int)xmin;
+    int maxtotal = total;
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) maxtotal = max(maxtotal, __shfl_xor(maxtotal, d));
+    for (int d = 32; d >= 4; d >>= 1) maxtotal = max(maxtotal, __shfl_xor(maxtotal, d));
     maxtotal = rli(maxtotal, 0);
+    const int nit = (maxtotal + 3) >> 2;
 
-    // Accumulators: lane = cell*4 + sub owns des[sub], des[sub+4] of its cell; sub 0 also des[8].
-    const int mycell = lane >> 2, sub = lane & 3;
     float acc_lo = 0.0f, acc_hi = 0.0f, acc_8 = 0.0f;
-    float2* rlist = &rec_lds[wv][0][0];
+    int cnt = 0;  // records in this cell's list (same value in the four lanes of the cell)
 
-    for (int t0 = 0; t0 < maxtotal; t0 += 64) {
-      // ---- phase 1: 64 samples of every cell's box, hits appended in scan order to the cell's list ----
-      int cnt_l = 0;  // lane c < 16: records of cell c in this round
-      int cntmax = 0;
-      for (int cg = 0; cg < 16; cg += 4) {
-        // stage A (4 cells): geometry, window test, and the gradient gathers issued back to back so
-        // that their latencies overlap (one dependent load per cell would serialise 16 L2 round trips)
-        bool in[4];
-        float nxa[4], nya[4], oxa[4], oya[4];
-        float2 cca[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int cell = cg + u;
-          const int tot_c = rli(total_l, cell);
-          const float ptx = rl(ptx_l, cell), pty = rl(pty_l, cell);
-          const float xmin = rl(xmin_l, cell), ymin = rl(ymin_l, cell);
-          const float inv = rl(inv_l, cell);
-          const int nxs = rli(nxs_l, cell);
-          oxa[u] = rl(offx_l, cell);
-          oya[u] = rl(offy_l, cell);
-          const int t = t0 + lane;
-          const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
-          const int sx = t - sy * nxs;
-          const float x = xmin + (float)sx, y = ymin + (float)sy;
-          const float dx = x - ptx, dy = y - pty;
-          nxa[u] = fmaf(crspt, dx, srspt * dy);
-          nya[u] = fmaf(crspt, dy, -(srspt * dx));
-          in[u] = (t < tot_c) && (fabsf(nxa[u]) < 1.0f) && (fabsf(nya[u]) < 1.0f);
-          cca[u] = gp[in[u] ? (int)y * width + (int)x : 0];
-        }
-        // stage B: weights, ordered append to the cell's list
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int cell = cg + u;
-          bool hit = false;
-          float theta = 0.0f, wt = 0.0f;
-          if (in[u]) {
-            const float nxn = fabsf(nxa[u]), nyn = fabsf(nya[u]);
-            const float dnx = nxa[u] + oxa[u], dny = nya[u] + oya[u];
-            const float ww = dm_expf(-0.125f * fmaf(dnx, dnx, dny * dny));
-            const float wx = 1.0f - nxn, wy = 1.0f - nyn;
-            wt = ww * wx * wy * cca[u].x;
-            theta = (anglef - cca[u].y) * rpi;
-            if (theta < 0) theta += 8.0f;
-            // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771)
-            hit = (theta >= 0.0f) && (theta < 8.0f);
-          }
-          const uint64_t mk = __ballot(hit);
-          if (hit) rlist[cell * 64 + __popcll(mk & ((1ull << lane) - 1ull))] = make_float2(theta, wt);
-          const int nrec = __popcll(mk);
-          if (lane == cell) cnt_l = nrec;
-          cntmax = max(cntmax, nrec);
-        }
+    auto update = [&](float theta, float w) {
+      const float c0 = __builtin_amdgcn_fmed3f(0.0f, jlo1 - theta, theta - jlom);  // ProgramCU.cu:1752-1753
+      acc_lo = fmaf(c0, w, acc_lo);
+      const float c1 = __builtin_amdgcn_fmed3f(0.0f, jhi1 - theta, theta - jhim);
+      acc_hi = fmaf(c1, w, acc_hi);
+      const float c8 = fmaxf(0.0f, theta - j8m);
+      acc_8 = fmaf(c8, w, acc_8);
+    };
+    auto drain = [&]() {
+      for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
+        const float4 ra = *reinterpret_cast<const float4*>(mylist + s0);
+        const float4 rb = *reinterpret_cast<const float4*>(mylist + s0 + 2);
+        update(ra.x, (s0 < cnt) ? ra.y : 0.0f);
+        update(ra.z, (s0 + 1 < cnt) ? ra.w : 0.0f);
+        update(rb.x, (s0 + 2 < cnt) ? rb.y : 0.0f);
+        update(rb.z, (s0 + 3 < cnt) ? rb.w : 0.0f);
       }
-      // ---- phase 2: the four lanes of a cell walk its list in order; one fmaf per record and lane ----
-      const int nmine = __shfl(cnt_l, mycell);
-      const float2* mylist = rlist + mycell * 64;
-      for (int step0 = 0; step0 < cntmax; step0 += 4) {
-        float2 r4[4];
+      cnt = 0;
+    };
+
+    for (int it0 = 0; it0 < nit; it0 += 4) {
+      if (__any(cnt > DL_CAP - 16)) drain();
+      // stage A (4 iterations): geometry, window test, and the gradient gathers issued back to back
+      bool in[4];
+      float nxa[4], nya[4];
+      float2 cca[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) r4[u] = mylist[min(step0 + u, 63)];  // issue the LDS reads together
+      for (int u = 0; u < 4; u++) {
+        const int t = (it0 + u) * 4 + sub;
+        const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
+        const int sx = t - __mul24(sy, nxs);  // box sides are far below 2^23: 24-bit multiplies are exact
+        const float x = xmin + (float)sx, y = ymin + (float)sy;
+        const float dx = x - ptx, dy = y - pty;
+        nxa[u] = fmaf(crspt, dx, srspt * dy);
+        nya[u] = fmaf(crspt, dy, -(srspt * dx));
+        in[u] = (t < total) & (fabsf(nxa[u]) < 1.0f) & (fabsf(nya[u]) < 1.0f);
+        cca[u] = gp[in[u] ? base + __mul24(sy, width) + sx : 0];
+      }
+      // stage B: weights, ordered append to the cell's list
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (step0 + u < nmine) {
-            const float2 r = r4[u];
-            const float fo = floorf(r.x);
-            const int fidx = (int)fo;
-            const float w1 = fo + 1.0f - r.x;   // ProgramCU.cu:1752
-            const float w2 = r.x - fo;          // ProgramCU.cu:1753
-            const bool is1 = ((fidx & 3) == sub);          // des[fidx]   += w1*weight
-            const bool is2 = (((fidx + 1) & 3) == sub);    // des[fidx+1] += w2*weight
-            const int tgt = is1 ? fidx : fidx + 1;
-            const float coef = is1 ? w1 : w2;
-            const float base = (tgt < 4) ? acc_lo : ((tgt < 8) ? acc_hi : acc_8);
-            const float upd = fmaf(coef, r.y, base);
-            const bool act = is1 || is2;
-            if (act && tgt < 4) acc_lo = upd;
-            else if (act && tgt < 8) acc_hi = upd;
-            else if (act) acc_8 = upd;
-          }
-        }
+      for (int u = 0; u < 4; u++) {
+        const float nxn = fabsf(nxa[u]), nyn = fabsf(nya[u]);
+        const float dnx = nxa[u] + offx, dny = nya[u] + offy;
+        const float ww = dm_expf(-0.125f * fmaf(dnx, dnx, dny * dny));
+        const float wx = 1.0f - nxn, wy = 1.0f - nyn;
+        const float wt = ww * wx * wy * cca[u].x;
+        float theta = (anglef - cca[u].y) * rpi;
+        theta = (theta < 0) ? theta + 8.0f : theta;
+        // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771)
+        const bool hit = in[u] & (theta >= 0.0f) & (theta < 8.0f);
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+        const uint32_t nib = (uint32_t)(mk >> (lane & 60)) & 15u;  // hits of this cell's four lanes
+        // misses go to the padding slot of the list (never read), so the chunk stays branch-free
+        mylist[hit ? cnt + __popc(nib & ((1u << sub) - 1u)) : DL_STRIDE - 1] = make_float2(theta, wt);
+        cnt += __popc(nib);
       }
     }
+    drain();
     if (sub == 0) acc_lo += acc_8;  // des[0] += des[8], ProgramCU.cu:1776
     if (dp.half_sift) {
       dl[wv][mycell * 4 + sub] = acc_lo + acc_hi;  // des[k] += des[k+4], ProgramCU.cu:1782-1785
