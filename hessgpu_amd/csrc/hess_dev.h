@@ -31,6 +31,8 @@ struct OctGeom {
   int mask_base;        // first mask word of this octave in the per-image mask array
   int tiles_x;          // extrema tiles (256 x 8 px) per row of tiles
   int tile_base;        // first extrema tile of this octave in the per-image tile order
+  int strips;           // streaming extrema scan: 124-column strips per row (k_detect.hip)
+  int stream_base;      // first streaming workgroup of this octave in the per-image order
 };
 
 struct Geom {
@@ -39,6 +41,7 @@ struct Geom {
   int NR;               // rows per image in list order: dog * sum_o h_o
   int NM;               // mask words per image
   int ntiles;           // extrema tiles per image
+  int nstream;          // streaming extrema workgroups per image
   OctGeom o[kMaxOct];
 };
 

@@ -358,6 +358,160 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
   }
 }
 
+// ---- streaming extrema scan (pass 1, default for dog <= 5): registers instead of an LDS tile ----
+// One wavefront marches down a strip of 124 owned columns (lane j holds columns x0-2+2j, x0-1+2j of
+// every det-H level; lanes 0 and 63 only supply the halo column) over SX_ROWS rows.  Per new row and
+// level it forms the horizontal 3-max / 3-min (neighbours from the adjacent lanes by DPP wave shifts)
+// and keeps them for the last three rows, so the 26-neighbour maximum of a pixel is
+//   max3( max over 3 rows of the level below, same of the level above,
+//         max3(row above, row below, left/right) of its own level )
+// -- about 65 VALU operations per pixel for all levels together, every level-pixel loaded from HBM
+// once per strip segment, no LDS traffic and no barriers.  The necessary condition "beyond the first
+// threshold and >= all 26 neighbours or <= all of them" is the same superset filter as in
+// extrema_mark_kernel; survivors are queued (64 per batch, all lanes busy) for the exact
+// order-dependent test key_eval, which sets positional mask bits and row counts with atomics (the
+// masks are zeroed before the launch).
+constexpr int SX_PITCH = 124, SX_ROWS = 24, SX_QCAP = 128;
+
+__device__ __forceinline__ float lane_prev(float v) {  // lane i <- lane i-1 (lane 0: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v) {  // lane i <- lane i+1 (lane 63: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+template <int DOG>
+__global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParams dp, const float* deth,
+                                                             unsigned long long* rowmask, int* rowcnt) {
+  constexpr int NLV = DOG + 2;
+  __shared__ uint32_t queue[4][SX_QCAP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  int o = 0;
+  for (int k = 1; k < g.noct; k++)
+    if (g.o[k].stream_base <= (int)blockIdx.x) o = k;
+  const OctGeom& og = g.o[o];
+  const int task = ((int)blockIdx.x - og.stream_base) * 4 + wv;
+  const int seg = task / og.strips, strip = task - seg * og.strips;
+  const int ys = seg * SX_ROWS;
+  if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
+  const int ye = min(ys + SX_ROWS, og.h);
+  const int cx = strip * SX_PITCH - 2 + 2 * lane;  // this lane's first column (even)
+  const bool col_in = cx >= 0 && cx < og.wa;
+  const int wa = og.wa, h = og.h;
+  const long long lstep = (long long)g.B * og.plane;
+  const float* base = deth + og.lvl_off + (long long)b * og.plane;  // level l at base + l*lstep
+  // a pixel is tested if it is interior (ProgramCU.cu:700-705) and owned by this lane
+  const bool own = lane >= 1 && lane <= 62;
+  const bool cv0 = own && cx > 0 && cx < wa - 1;
+  const bool cv1 = own && cx + 1 > 0 && cx + 1 < wa - 1;
+  uint32_t* q = queue[wv];
+  int qn = 0;
+
+  auto load_row = [&](int yy, float2 (&dst)[NLV]) {
+    // rows/columns outside the plane are only ever neighbours of pixels that are not tested: any
+    // finite value will do, so the address is clamped instead of the value being selected
+    const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+    const long long off = (long long)yc * wa + (col_in ? cx : 0);
+#pragma unroll
+    for (int l = 0; l < NLV; l++) dst[l] = *reinterpret_cast<const float2*>(base + l * lstep + off);
+  };
+  auto process = [&](uint32_t e, bool active) {
+    const int l = e >> 28, row = (e >> 14) & 0x3FFF, col = e & 0x3FFF;
+    const float* C = base + l * lstep;
+    if (active && key_eval<false>(C, C - lstep, C + lstep, nullptr, wa, row * wa + col, dp, nullptr)) {
+      atomicOr(&rowmask[(long long)b * g.NM + og.mask_base + ((l - 1) * h + row) * og.w64 + (col >> 6)],
+               1ull << (col & 63));
+      atomicAdd(&rowcnt[(long long)b * g.NR + og.row_base + (l - 1) * h + row], 1);
+    }
+  };
+
+  // ring of the last three rows: horizontal 3-max/3-min of every level, raw centre values and
+  // left/right max/min of the detection levels
+  float hmx[NLV][3][2], hmn[NLV][3][2];
+  float rc[DOG][3][2], lmx[DOG][3][2], lmn[DOG][3][2];
+  auto ingest = [&](const float2 (&cur)[NLV], int slot) {
+#pragma unroll
+    for (int l = 0; l < NLV; l++) {
+      const float a0 = cur[l].x, a1 = cur[l].y;
+      const float L = lane_prev(a1), R = lane_next(a0);
+      hmx[l][slot][0] = max3f(L, a0, a1); hmx[l][slot][1] = max3f(a0, a1, R);
+      hmn[l][slot][0] = min3f(L, a0, a1); hmn[l][slot][1] = min3f(a0, a1, R);
+      if (l >= 1 && l <= DOG) {
+        rc[l - 1][slot][0] = a0; rc[l - 1][slot][1] = a1;
+        lmx[l - 1][slot][0] = fmaxf(L, a1); lmx[l - 1][slot][1] = fmaxf(a0, R);
+        lmn[l - 1][slot][0] = fminf(L, a1); lmn[l - 1][slot][1] = fminf(a0, R);
+      }
+    }
+  };
+
+  float2 cur[NLV], nxt[NLV];
+  load_row(ys - 1, cur);
+  load_row(ys, nxt);
+  ingest(cur, 0);
+#pragma unroll
+  for (int l = 0; l < NLV; l++) cur[l] = nxt[l];
+  load_row(ys + 1, nxt);
+  ingest(cur, 1);
+
+  for (int y0 = ys; y0 < ye; y0 += 3) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int y = y0 + s;
+      if (y < ye) {  // wavefront-uniform
+        // ring slots: row y-1 -> s, row y -> s+1, row y+1 (arriving now) -> s+2 (mod 3)
+        constexpr int kRing[5] = {0, 1, 2, 0, 1};
+        const int sa = kRing[s], sc = kRing[s + 1], sb = kRing[s + 2];
+#pragma unroll
+        for (int l = 0; l < NLV; l++) cur[l] = nxt[l];
+        load_row(y + 2, nxt);  // prefetch: consumed in the next iteration
+        ingest(cur, sb);
+        if (y > 0 && y < h - 1) {  // wavefront-uniform
+          float m9x[NLV][2], m9n[NLV][2];
+#pragma unroll
+          for (int l = 0; l < NLV; l++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              m9x[l][c] = max3f(hmx[l][sa][c], hmx[l][sc][c], hmx[l][sb][c]);
+              m9n[l][c] = min3f(hmn[l][sa][c], hmn[l][sc][c], hmn[l][sb][c]);
+            }
+          uint32_t cand = 0;
+#pragma unroll
+          for (int li = 0; li < DOG; li++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              const int l = li + 1;
+              const float r = rc[li][sc][c];
+              const float nx = max3f(m9x[l - 1][c], m9x[l + 1][c], max3f(hmx[l][sa][c], hmx[l][sb][c], lmx[li][sc][c]));
+              const float nn = min3f(m9n[l - 1][c], m9n[l + 1][c], min3f(hmn[l][sa][c], hmn[l][sb][c], lmn[li][sc][c]));
+              const bool f = (c ? cv1 : cv0) & (fabsf(r) > dp.thr0) & ((r >= nx) | (r <= nn));
+              cand |= f ? (1u << (li * 2 + c)) : 0u;
+            }
+          if (__any(cand != 0)) {
+            for (int k = 0; k < 2 * DOG; k++) {
+              const bool f = (cand >> k) & 1u;
+              const uint64_t m = __builtin_amdgcn_ballot_w64(f);
+              if (m == 0) continue;
+              if (f) q[qn + __popcll(m & ((1ull << lane) - 1ull))] =
+                  ((uint32_t)((k >> 1) + 1) << 28) | ((uint32_t)y << 14) | (uint32_t)(cx + (k & 1));
+              qn += __popcll(m);
+              if (qn >= 64) {
+                process(q[lane], true);
+                const uint32_t tail = q[64 + lane];
+                qn -= 64;
+                if (lane < qn) q[lane] = tail;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (qn > 0) process(q[lane < qn ? lane : 0], lane < qn);
+}
+
 // Extrema scan pass 2: one thread per detection.  Thread i of image b finds its row by binary search
 // in the exclusive row offsets, its column as the (i - offset)-th set bit of the row's mask words,
 // recomputes the keypoint (all lanes busy) and writes raw[i]: row-major order by construction.
@@ -635,7 +789,21 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                          const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
   (void)gauss;
-  hipMemsetAsync(rowcnt, 0, (size_t)batch * g.NR * sizeof(int), st);
+  (void)hipMemsetAsync(rowcnt, 0, (size_t)batch * g.NR * sizeof(int), st);
+  if (g.dog <= 5) {  // streaming scan; sets mask bits with atomics
+    (void)hipMemsetAsync(rowmask, 0, (size_t)batch * g.NM * sizeof(uint64_t), st);
+    unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);
+    const dim3 grid(g.nstream, batch), blk(256);
+    switch (g.dog) {
+      case 1: hipLaunchKernelGGL(extrema_stream_kernel<1>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+      case 2: hipLaunchKernelGGL(extrema_stream_kernel<2>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+      case 3: hipLaunchKernelGGL(extrema_stream_kernel<3>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+      case 4: hipLaunchKernelGGL(extrema_stream_kernel<4>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+      default: hipLaunchKernelGGL(extrema_stream_kernel<5>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+    }
+    return;
+  }
+  // more than 5 detection levels per octave: LDS-tiled scan (level count is a run-time value there)
   const size_t lds = (size_t)(g.dog + 2) * (EX_TR + 2) * EX_STRIDE * sizeof(float);
   static size_t lds_allowed = 0;  // dog >= 4 needs more than the default 64 KB of dynamic LDS
   if (lds > lds_allowed) {
