@@ -19,6 +19,12 @@ constexpr int kMaxOct = 16;
 constexpr int kMaxDog = 10;
 constexpr int kMaxLev = kMaxDog + 2;
 constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH, ProgramCU.cu:42
+// streaming extrema scan (k_detect.hip): owned columns per strip, rows per wavefront segment
+constexpr int kStreamPitch = 124;
+#ifndef HESS_STREAM_ROWS
+#define HESS_STREAM_ROWS 24
+#endif
+constexpr int kStreamRows = HESS_STREAM_ROWS;
 constexpr int kHistBins = 32768;  // abs(half) keys of the top-K selection
 
 struct OctGeom {

@@ -285,9 +285,9 @@ int plan(hess_ctx* c, int width, int height, int batch) {
     og.tiles_x = (og.wa + 127) / 128;  // EX_TC columns per extrema tile (k_detect.hip)
     og.tile_base = g.ntiles;
     g.ntiles += og.tiles_x * ((og.h + 3) / 4);  // EX_TR rows per extrema tile (k_detect.hip)
-    og.strips = (og.wa + 123) / 124;            // SX_PITCH columns per strip, SX_ROWS rows per segment,
-    og.stream_base = g.nstream;                 // four (strip, segment) tasks per workgroup
-    g.nstream += (og.strips * ((og.h + 23) / 24) + 3) / 4;
+    og.strips = (og.wa + kStreamPitch - 1) / kStreamPitch;
+    og.stream_base = g.nstream;  // four (strip, segment) tasks per workgroup
+    g.nstream += (og.strips * ((og.h + kStreamRows - 1) / kStreamRows) + 3) / 4;
     lvl += (long long)c->sch.level_num * B * og.plane;
     gt += (long long)g.dog * B * og.plane;
     rows += g.dog * og.h;

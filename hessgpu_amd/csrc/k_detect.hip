@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
 // extrema_mark_kernel; survivors are queued (64 per batch, all lanes busy) for the exact
 // order-dependent test key_eval, which sets positional mask bits and row counts with atomics (the
 // masks are zeroed before the launch).
-constexpr int SX_PITCH = 124, SX_ROWS = 24, SX_QCAP = 128;
+constexpr int SX_PITCH = kStreamPitch, SX_ROWS = kStreamRows, SX_QCAP = 128;
 
 __device__ __forceinline__ float lane_prev(float v) {  // lane i <- lane i-1 (lane 0: 0)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));

@@ -175,6 +175,10 @@ def test_parity_4096_half_topk65536(gpu_ctx_factory):
     dict(compute_descriptors=0),
     dict(lowe_origin=1, dog_threshold=0.004, edge_threshold=5.0),
     dict(dog_level_num=4),
+    dict(dog_level_num=1),
+    dict(dog_level_num=2),
+    dict(dog_level_num=5),
+    dict(dog_level_num=6),   # more than 5 levels: LDS-tiled extrema scan instead of the streaming one
     dict(first_octave=1),
     dict(octave_num=2),
     dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=100),
@@ -213,6 +217,18 @@ def test_parity_input_formats(gpu_ctx_factory, dtype, fmt):
     gk, gd = g.fetch(0)
     ok, od = o.fetch(0)
     _assert_same_features(gk, gd, ok, od, dtype)
+
+
+@pytest.mark.parametrize("w,h", [(251, 50), (124, 24), (125, 25), (372, 73), (1000, 97)])
+def test_parity_noise_ragged(gpu_ctx_factory, w, h):
+    """Dense extrema on sizes that straddle the extrema scan's strip (124 columns) and segment
+    (24 rows) boundaries; a low threshold keeps the candidate queues of the scan full."""
+    rng = np.random.RandomState(w * 131 + h)
+    img = (rng.rand(2, h, w) * 255).astype(np.uint8)
+    kw = dict(dog_threshold=0.0005, edge_threshold=50.0)
+    g = gpu_ctx_factory(**kw)
+    o = OracleSession(threads=8, **kw)
+    _compare_all(g, o, img, f"noise {w}x{h}")
 
 
 def test_edge_cases(gpu_ctx_factory):
