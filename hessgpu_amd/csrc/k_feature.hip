@@ -40,7 +40,9 @@ __device__ __forceinline__ void level_of(const Geom& g, int li, int* o, int* l) 
 __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams op, const RawKey* list,
                                                           const int* list_total, int cap_list, const float* got,
                                                           FRec* recs, int* ocount) {
+  __shared__ __attribute__((aligned(16))) float4 orec[4][64];  // per wavefront: (bin, gradient, weight) records
   const int lane = threadIdx.x & 63;
+  float4* const myrec = orec[threadIdx.x >> 6];
   const int b = blockIdx.y;
   const int n = list_total[b];
   const int nwaves = gridDim.x * 4;
@@ -85,34 +87,40 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
       const int total = nxs * nys;
 
       float vote = 0.0f;  // lane j < 36 owns vote[j]
+      const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
+      const int base = (int)ymin * width + (int)xmin;  // (int)y * width + (int)x of sample (0, 0)
       for (int t0 = 0; t0 < total; t0 += 64) {
+        // 64 samples of the window in scan order, branch-free; the ones inside the circle are
+        // compacted, in order, into the wavefront's record list
         const int t = t0 + lane;
-        bool inside = false;
-        int bin = 0;
-        float gx = 0.0f, e = 0.0f;
-        if (t < total) {
-          const int iy = t / nxs, ix = t - iy * nxs;
-          const float x = xmin + (float)ix, y = ymin + (float)iy;
-          float dy = y - ky;
-          dy *= dy;
-          const float dx = x - kx;
-          const float sq_dist = fmaf(dx, dx, dy);
-          if (!(sq_dist >= dist_threshold)) {
-            inside = true;
-            const float2 gv = gp[(int)y * width + (int)x];  // tex2D point fetch, ProgramCU.cu:1351
-            bin = (int)floorf(gv.y * ten_degree_per_radius);
-            if (bin < 0) bin += 36;
-            gx = gv.x;
-            e = dm_expf(sq_dist * factor);
-          }
-        }
-        uint64_t m = __ballot(inside);
-        while (m) {  // ascending lane order = the reference's sample order
-          const int j = __builtin_ctzll(m);
-          m &= m - 1;
-          const int bj = rli(bin, j);
-          const float gj = rl(gx, j), ej = rl(e, j);
-          if (lane == bj) vote = fmaf(gj, ej, vote);  // ProgramCU.cu:1359
+        const int iy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
+        const int ix = t - __mul24(iy, nxs);
+        const float x = xmin + (float)ix, y = ymin + (float)iy;
+        float dy = y - ky;
+        dy *= dy;
+        const float dx = x - kx;
+        const float sq_dist = fmaf(dx, dx, dy);
+        const bool inside = (t < total) & !(sq_dist >= dist_threshold);
+        const float2 gv = gp[inside ? base + __mul24(iy, width) + ix : 0];  // tex2D point fetch, ProgramCU.cu:1351
+        int bin = (int)floorf(gv.y * ten_degree_per_radius);
+        bin = (bin < 0) ? bin + 36 : bin;
+        const float e = dm_expf(sq_dist * factor);
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(inside);
+        const int nin = __popcll(mk);
+        if (inside) myrec[__popcll(mk & ((1ull << lane) - 1ull))] = make_float4(__int_as_float(bin), gv.x, e, 0.0f);
+        // lane j adds the records of bin j in list order = the reference's sample order
+        // (ProgramCU.cu:1359: vote[bin] += gradient * weight); for the other bins the coefficient is 0
+        // and fmaf(0, e, vote) == vote (votes and weights are non-negative and finite)
+        for (int k0 = 0; k0 < nin; k0 += 4) {
+          float4 r[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) r[u] = myrec[min(k0 + u, 63)];  // same address in all lanes: broadcast
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (k0 + u < nin) {  // wavefront-uniform
+              const float cgx = (__float_as_int(r[u].x) == lane) ? r[u].y : 0.0f;
+              vote = fmaf(cgx, r[u].z, vote);
+            }
         }
       }
       // six circular 3-tap box passes (ProgramCU.cu:1364-1379): each pass reads only old values
