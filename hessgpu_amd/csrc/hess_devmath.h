@@ -70,6 +70,46 @@ __device__ __forceinline__ float dm_atan2f(float y, float x) {
   return r;
 }
 
+// Two-wide forms of dm_atan01 / dm_atan2f: the same operations per component (IEEE division, fused
+// multiply-adds in the same order) and branch-free: for (0,0) the quotient is 0/1 = 0 and every later
+// step leaves 0, as the early return of the scalar form does.  The 2-vectors compile to packed FP32
+// instructions; on gfx950 those issue at half the rate of the scalar ones (tools/micro/valu_rate.hip:
+// v_pk_fma_f32 5.3 vs v_fma_f32 2.7 cycles per wavefront instruction), so this form is about straight-line
+// code, not about arithmetic throughput.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f v2_splat(float x) { return (v2f){x, x}; }
+
+__device__ __forceinline__ v2f dm_atan01_x2(v2f t) {
+  const v2f z = t * t;
+  v2f q = v2_splat(-0.0017890612361952662f);
+  q = v2_fma(q, z, v2_splat(0.010897884145379066f));
+  q = v2_fma(q, z, v2_splat(-0.03115503303706646f));
+  q = v2_fma(q, z, v2_splat(0.057945046573877335f));
+  q = v2_fma(q, z, v2_splat(-0.08403480052947998f));
+  q = v2_fma(q, z, v2_splat(0.10952533036470413f));
+  q = v2_fma(q, z, v2_splat(-0.14264392852783203f));
+  q = v2_fma(q, z, v2_splat(0.19998574256896973f));
+  q = v2_fma(q, z, v2_splat(-0.33333301544189453f));
+  q = q * z;
+  return v2_fma(q, t, t);
+}
+
+__device__ __forceinline__ v2f dm_atan2f_x2(v2f y, v2f x) {
+  const v2f ax = {fabsf(x.x), fabsf(x.y)}, ay = {fabsf(y.x), fabsf(y.y)};
+  const bool g0 = ax.x > ay.x, g1 = ax.y > ay.y;
+  const v2f mx = {g0 ? ax.x : ay.x, g1 ? ax.y : ay.y};
+  const v2f mn = {g0 ? ay.x : ax.x, g1 ? ay.y : ax.y};
+  const v2f den = {mx.x == 0.0f ? 1.0f : mx.x, mx.y == 0.0f ? 1.0f : mx.y};
+  v2f r = dm_atan01_x2(mn / den);
+  const v2f r1 = v2_splat(1.57079632679489662f) - r;
+  r = (v2f){ay.x > ax.x ? r1.x : r.x, ay.y > ax.y ? r1.y : r.y};
+  const v2f r2 = v2_splat(3.14159265358979324f) - r;
+  r = (v2f){x.x < 0.0f ? r2.x : r.x, x.y < 0.0f ? r2.y : r.y};
+  r = (v2f){y.x < 0.0f ? -r.x : r.x, y.y < 0.0f ? -r.y : r.y};
+  return r;
+}
+
 __device__ __forceinline__ void dm_sincosf(float a, float* s, float* c) {
   float k = rintf(a * 0.636619772367581343f);
   float r = fmaf(k, -1.5703125f, a);

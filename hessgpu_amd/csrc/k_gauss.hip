@@ -158,21 +158,26 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
       }
       float hv[8];
       float2 gv[8];
-      const bool want_got = a.got_src != nullptr;
+      const bool want_got = a.got_src != nullptr;  // block-uniform
+      // two pixels at a time on 2-vectors, no per-pixel branches
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const float v11 = U[j], v12 = U[j + 1], v13 = U[j + 2];
-        const float v21 = M[j], v22 = M[j + 1], v23 = M[j + 2];
-        const float v31 = D[j], v32 = D[j + 1], v33 = D[j + 2];
-        const float Lxx = fmaf(-2.0f, v22, v21) + v23;      // ProgramCU.cu:536
-        const float Lyy = fmaf(-2.0f, v22, v12) + v32;      // :537
-        const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;  // :538
-        hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * a.norm_src;  // :553
+      for (int j = 0; j < 8; j += 2) {
+#define HESS_V2(A, K) ((v2f){A[(K)], A[(K) + 1]})
+        const v2f v11 = HESS_V2(U, j), v12 = HESS_V2(U, j + 1), v13 = HESS_V2(U, j + 2);
+        const v2f v21 = HESS_V2(M, j), v22 = HESS_V2(M, j + 1), v23 = HESS_V2(M, j + 2);
+        const v2f v31 = HESS_V2(D, j), v32 = HESS_V2(D, j + 1), v33 = HESS_V2(D, j + 2);
+#undef HESS_V2
+        const v2f Lxx = v2_fma(v2_splat(-2.0f), v22, v21) + v23;   // ProgramCU.cu:536
+        const v2f Lyy = v2_fma(v2_splat(-2.0f), v22, v12) + v32;   // :537
+        const v2f Lxy = (v13 - v11 + v31 - v33) * v2_splat(0.25f);  // :538
+        const v2f dh = v2_fma(Lxx, Lyy, -(Lxy * Lxy)) * v2_splat(a.norm_src);  // :553
+        hv[j] = dh.x; hv[j + 1] = dh.y;
         if (want_got) {
-          const float dx = v23 - v21, dy = v32 - v12;       // :556-557
-          const float gradient = 0.5f * sqrtf(fmaf(dx, dx, dy * dy));
-          gv[j].x = gradient;
-          gv[j].y = (gradient == 0.0f) ? 0.0f : dm_atan2f(dy, dx);
+          const v2f dx = v23 - v21, dy = v32 - v12;                 // :556-557
+          const v2f gradient = v2_splat(0.5f) * __builtin_elementwise_sqrt(v2_fma(dx, dx, dy * dy));
+          const v2f th = dm_atan2f_x2(dy, dx);
+          gv[j].x = gradient.x;     gv[j].y = (gradient.x == 0.0f) ? 0.0f : th.x;
+          gv[j + 1].x = gradient.y; gv[j + 1].y = (gradient.y == 0.0f) ? 0.0f : th.y;
         }
       }
       const long long o = img * (long long)w * h + idx;
