@@ -28,11 +28,20 @@ struct HessArgs {
   float* deth;
   float2* got;
   int wa, h, plane, B, dog, level_first, batch;
+  float inv_groups;  // 1 / (wa/4)
   long long lvl_off, got_off;
   float norm[kMaxLev];  // sigma_l^4 (host passes sigma^2, wrapper squares it: ProgramCU.cu:592)
 };
 
 __device__ __forceinline__ float tex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
+
+// neighbour lanes by DPP wave shifts (one VALU move each; no LDS crossbar round trip)
+__device__ __forceinline__ float lane_prev(float v) {  // lane i <- lane i-1 (lane 0: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v) {  // lane i <- lane i+1 (lane 63: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
 
 // 4 pixels per thread, 16-byte loads/stores.  Neighbour addressing follows the reference's 1-D
 // linear texture: index +-1 wraps across row ends, anything outside [0, wa*h) reads 0.
@@ -40,8 +49,12 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
   const int groups_per_row = a.wa >> 2;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= groups_per_row * a.h) return;
-  const int row = gid / groups_per_row;
-  const int x = (gid - row * groups_per_row) << 2;
+  // row = gid / groups_per_row without an integer division: float estimate, then one exact correction step
+  int row = (int)(((float)gid + 0.5f) * a.inv_groups);
+  int rem = gid - row * groups_per_row;
+  if (rem < 0) { row--; rem += groups_per_row; }
+  else if (rem >= groups_per_row) { row++; rem -= groups_per_row; }
+  const int x = rem << 2;
   const int z = blockIdx.y;  // l * batch + b
   const int l = a.level_first + z / a.batch, b = z % a.batch;
   const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
@@ -68,8 +81,8 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
   {
     const int lane = threadIdx.x & 63;
     const int nthreads = groups_per_row * a.h;
-    const float ul = __shfl_up(U[4], 1), ml = __shfl_up(M[4], 1), dl = __shfl_up(D[4], 1);
-    const float ur = __shfl_down(U[1], 1), mr = __shfl_down(M[1], 1), dr = __shfl_down(D[1], 1);
+    const float ul = lane_prev(U[4]), ml = lane_prev(M[4]), dl = lane_prev(D[4]);
+    const float ur = lane_next(U[1]), mr = lane_next(M[1]), dr = lane_next(D[1]);
     U[0] = ul; M[0] = ml; D[0] = dl;
     U[5] = ur; M[5] = mr; D[5] = dr;
     if (lane == 0) {
@@ -373,12 +386,6 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
 // masks are zeroed before the launch).
 constexpr int SX_PITCH = kStreamPitch, SX_ROWS = kStreamRows, SX_QCAP = 128;
 
-__device__ __forceinline__ float lane_prev(float v) {  // lane i <- lane i-1 (lane 0: 0)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_next(float v) {  // lane i <- lane i+1 (lane 63: 0)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
-}
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
@@ -780,6 +787,7 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
   a.gauss = gauss; a.deth = deth; a.got = reinterpret_cast<float2*>(got);
   a.wa = og.wa; a.h = og.h; a.plane = og.plane; a.B = g.B; a.dog = g.dog; a.level_first = level_first;
   a.batch = batch; a.lvl_off = og.lvl_off; a.got_off = og.got_off;
+  a.inv_groups = 1.0f / (float)(og.wa >> 2);
   for (int l = 0; l < g.dog + 2; l++) a.norm[l] = norms[l];
   const int groups = (og.wa >> 2) * og.h;
   hipLaunchKernelGGL(hessian_kernel, dim3((groups + 255) / 256, (level_last - level_first + 1) * batch), dim3(256),
