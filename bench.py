@@ -63,12 +63,20 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1
+    # HESS_BENCH_FORCE_DIST=1 runs the RCCL gather path with a single rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("HESS_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as tdist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group(backend="nccl", device_id=dev)
+        # per-image counts travel over a gloo side group (host, loopback: one node), the payload over RCCL
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            hdist.enable_host_count_exchange()
+        except Exception as e:  # same environment on every rank: all ranks fall back together
+            if rank == 0:
+                print(f"bench.py: gloo side group unavailable ({e}); counts go through RCCL", file=sys.stderr)
 
     B = args.batch
     nd = max(1, min(args.distinct, B))

@@ -5,8 +5,10 @@ per device, TestWin/MultiThreadSIFT.cpp:231-244, or one TCP server process per G
 ServerSiftGPU.cpp:156-194).  Here: one process per GPU, image i of a batch goes to the rank that
 owns the contiguous block containing i, each rank runs the whole path locally, and the only
 exchange step is the gather of the variable-length feature lists to one rank -- an all_gather of
-the per-image counts followed by one padded gather of keypoints and one of descriptors
-(torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+the per-image counts (a few integers that are already on the host: over a gloo side group when
+enable_host_count_exchange() was called, else through the data group) followed by one padded gather
+of keypoints and one of descriptors (torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs,
+"gloo" in the CPU tests).
 """
 import numpy as np
 import torch
@@ -22,6 +24,43 @@ def shard_range(n_items, rank, world):
     return first, first + base + (1 if rank < rem else 0)
 
 
+_count_group = {}  # data group (None = default) -> gloo side group for the count exchange
+
+
+def enable_host_count_exchange(group=None):
+    """Create a gloo side group for the per-image counts (collective: call on every rank, once).
+
+    The counts are on the host already (hess_count); exchanging them over gloo keeps the GPU out of the
+    control step.  Measured in bench.py on MI355X with three pipelined contexts: RCCL all_gather of the
+    counts + event wait = -7 % throughput (the host waits for a tiny kernel queued behind three streams of
+    long ones), gloo = no measurable cost."""
+    ranks = dist.get_process_group_ranks(group) if group is not None else None
+    _count_group[group] = dist.new_group(ranks=ranks, backend="gloo")
+
+
+def _exchange_counts(counts, dev, world, group):
+    """all_gather of the per-image counts -> list[world][n_local] of ints."""
+    local = torch.tensor(counts, dtype=torch.int32)
+    side = _count_group.get(group)
+    if dev.type != "cuda" or side is not None:
+        allc = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(allc, local, group=side if dev.type == "cuda" else group)
+        return [c.tolist() for c in allc]
+    # no side group: through the device, with pinned buffers and asynchronous copies (a synchronous copy
+    # from pageable memory stalls every stream of the device on ROCm)
+    pin_local = local.pin_memory()
+    dlocal = torch.empty(len(counts), dtype=torch.int32, device=dev)
+    dlocal.copy_(pin_local, non_blocking=True)
+    allc = torch.empty((world, len(counts)), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(allc, dlocal, group=group)
+    pin_all = torch.empty((world, len(counts)), dtype=torch.int32).pin_memory()
+    pin_all.copy_(allc, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    done.synchronize()
+    return pin_all.tolist()
+
+
 def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     """Gather per-image feature lists to rank `dst`.
 
@@ -34,15 +73,13 @@ def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = keys_u8.device
-    local = torch.tensor(counts, dtype=torch.int32, device=dev)
-    allc = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(allc, local, group=group)
-    all_counts = [c.tolist() for c in allc]
+    all_counts = _exchange_counts(counts, dev, world, group)
     totals = [int(sum(c)) for c in all_counts]
     pad = max(max(totals), 1)
 
     def padded(t, width, dtype):
-        out = torch.zeros((pad, width), dtype=dtype, device=dev)
+        # rows beyond the rank's own total are never looked at on dst: no need to clear them
+        out = torch.empty((pad, width), dtype=dtype, device=dev)
         if t is not None and t.shape[0]:
             out[: t.shape[0]] = t
         return out

@@ -61,5 +61,13 @@ def test_device_results_are_packed_and_gather_over_nccl(gpu_ctx_factory):
         hd = np.concatenate([g.fetch(b)[1] for b in range(4)])
         assert np.array_equal(gk[0].cpu().numpy(), hk)
         assert np.array_equal(gd[0].cpu().numpy().view(np.uint32), hd.view(np.uint32))
+        # same gather with the counts exchanged over the gloo side group (what bench.py does)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        hdist.enable_host_count_exchange()
+        allc2, gk2, gd2 = hdist.gather_feature_lists(counts, keys, desc, dst=0)
+        assert allc2 == [counts]
+        assert np.array_equal(gk2[0].cpu().numpy(), hk)
+        assert np.array_equal(gd2[0].cpu().numpy().view(np.uint32), hd.view(np.uint32))
     finally:
+        hdist._count_group.clear()
         dist.destroy_process_group()
