@@ -62,6 +62,25 @@ def test_set_keypoints_then_run_on_another_image(gpu_ctx_factory):
     _same(g2, o2, "list larger than top-K")
 
 
+def test_keypoints_at_borders_and_corners(gpu_ctx_factory):
+    """User keypoints on and beyond the image border: sample boxes clipped to one or two columns/rows
+    or to nothing, at small and large scales, with and without given orientations."""
+    img = fixtures.load_rgb("sunflowers.png")   # 768 x 323: odd sizes in every octave
+    h, w = img.shape[:2]
+    pts = []
+    for x in (0.0, 0.6, 1.4, 2.5, w / 2.0, w - 2.5, w - 1.4, w - 0.6, float(w)):
+        for y in (0.0, 0.7, 1.6, h / 2.0, h - 1.6, h - 0.7, float(h)):
+            for sc in (0.8, 1.7, 4.2, 11.0, 37.0):
+                pts.append((x, y, sc, (x * 0.37 + y * 0.11 + sc) % 6.28))
+    keys = np.zeros(len(pts), dtype=_abi.KEYPOINT_DTYPE)
+    keys["x"], keys["y"], keys["s"], keys["o"] = (np.array(v, dtype=np.float32) for v in zip(*pts))
+    for have_orientation in (1, 0):
+        g, o = _pair(gpu_ctx_factory)
+        g.run(img[None]); o.run(img[None])
+        assert g.run_keypoints(keys, have_orientation) == o.run_keypoints(keys, have_orientation) == len(keys)
+        _same(g, o, f"border keypoints orient={have_orientation}")
+
+
 def test_keypoint_list_errors(gpu_ctx_factory):
     from hessgpu_amd.session import HessError
 
