@@ -56,7 +56,8 @@ class HessParams(C.Structure):
         ("tex_max_dim", C.c_int32),
         ("auto_downscale", C.c_int32),
         ("verbose", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("dynamic_indexing", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 

@@ -100,6 +100,7 @@ struct DescParams {
   int lowe_origin;
   float octave_sigma;   // 2^ds (PyramidCU.cpp:746-748)
   int dog;
+  int dynamic_indexing;  // -di: theta == 8.0 goes to des[8] (ProgramCU.cu:1755-1759) instead of being dropped
 };
 
 // ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------

@@ -532,6 +532,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.lowe_origin = p.lowe_origin;
   dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;  // PyramidCU.cpp:746-748
   dsp.dog = g.dog;
+  dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
   {
     ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
     launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
@@ -643,6 +644,7 @@ int enqueue_user(hess_ctx* c) {
   dsp.lowe_origin = p.lowe_origin;
   dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
   dsp.dog = g.dog;
+  dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);

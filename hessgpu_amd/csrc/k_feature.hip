@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const float jlo1 = (float)(sub + 1), jlom = (float)(sub - 1);
   const float jhi1 = (float)(sub + 5), jhim = (float)(sub + 3);
   const float j8m = (sub == 0) ? 7.0f : 1.0e6f;
+  const float theta_end = dp.dynamic_indexing ? 8.00000095f : 8.0f;  // next float after 8: admits theta == 8 only
 
   for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
     const int src = fsrc[(long long)b * cap_feat + m];
@@ -444,8 +445,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         const float wt = ww * wx * wy * cca[u].x;
         float theta = (anglef - cca[u].y) * rpi;
         theta = (theta < 0) ? theta + 8.0f : theta;
-        // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771)
-        const bool hit = in[u] & (theta >= 0.0f) & (theta < 8.0f);
+        // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771);
+        // with -di it adds w1*weight = weight to des[8] (:1755-1759; the write to des[9] adds 0) -- which is
+        // what the bin-8 coefficient max(0, theta - 7) gives once the record is let through
+        const bool hit = in[u] & (theta >= 0.0f) & (theta < theta_end);
         const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
         const uint32_t nib = (uint32_t)(mk >> (lane & 60)) & 15u;  // hits of this cell's four lanes
         // misses go to the padding slot of the list (never read), so the chunk stays branch-free

@@ -269,9 +269,10 @@ void SiftGPU::ParseParam(int argc, char** argv) {  // SiftGPU.cpp:855-1380
       }
       continue;
     }
-    if (k == "lcpu" || k == "lc" || k == "prep" || k == "nopr" || k == "exit" || k == "di" || k == "debu" ||
+    if (k == "lcpu" || k == "lc" || k == "prep" || k == "nopr" || k == "exit" || k == "debu" ||
         k == "k0" || k == "kx" || k == "da" || k == "fmc" || k == "nomc")
       continue;  // accepted, no effect on this backend
+    if (k == "di") { p.dynamic_indexing = 1; continue; }  // SiftGPU.cpp:1030-1032
     if (k == "sd") { if (!_initialized) p.compute_descriptors = 0; continue; }
     if (k == "b") { im->binary_sift = 1; continue; }
     if (k == "ads") { p.auto_downscale = 1; continue; }

@@ -81,7 +81,10 @@ typedef struct hess_params {
   int32_t tex_max_dim;          /* -maxd (0=default 3200)                                     */
   int32_t auto_downscale;       /* -ads                                                       */
   int32_t verbose;              /* 0 silent                                                   */
-  int32_t reserved[8];
+  int32_t dynamic_indexing;     /* -di  descriptor bins indexed dynamically (GlobalUtil.cpp:108,
+                                   ProgramCU.cu:1755-1771): a sample whose bin coordinate rounds up to
+                                   exactly 8.0 is then added to bin 8 (folded into bin 0), not dropped */
+  int32_t reserved[7];
 } hess_params;
 
 /* Binary-identical to SiftGPU::SiftKeypoint (SiftGPU.h:108-116): 24 bytes. */

@@ -581,7 +581,7 @@ static void compute_orientation_existing(const hess_cpu_ctx* c, frec* rec, const
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* ComputeDescriptor_Kernel<false,HALF>, ProgramCU.cu:1650-1804 + NormalizeDescriptor_Kernel
+/* ComputeDescriptor_Kernel<-di,HALF>, ProgramCU.cu:1650-1804 + NormalizeDescriptor_Kernel
  * :1950-2054.  `angle` is the un-mirrored float orientation handed to the kernel (key.w).    */
 
 static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float angle, const float* got,
@@ -631,9 +631,13 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
           int fidx = (int)fo;
           float weight1 = fo + 1.0f - theta;
           float weight2 = theta - fo;
-          if (fidx >= 0 && fidx < 8) { /* DYNAMIC_INDEXING = false: k==fidx for k<8 only */
+          if (fidx >= 0 && fidx < 8) { /* DYNAMIC_INDEXING = false: k==fidx for k<8 only (:1763-1771) */
             des[fidx] = fmaf(weight1, weight, des[fidx]);
             des[fidx + 1] = fmaf(weight2, weight, des[fidx + 1]);
+          } else if (fidx == 8 && c->p.dynamic_indexing) {
+            /* -di, DYNAMIC_INDEXING = true (:1755-1759): des[8] += weight1*weight; the reference also
+             * writes des[9] (one past the array) += weight2*weight = +0: not restated */
+            des[8] = fmaf(weight1, weight, des[8]);
           }
         }
       }

@@ -81,6 +81,42 @@ def test_keypoints_at_borders_and_corners(gpu_ctx_factory):
         _same(g, o, f"border keypoints orient={have_orientation}")
 
 
+def test_dynamic_indexing_option(gpu_ctx_factory):
+    """-di (GlobalUtil::_UseDynamicIndexing): a sample whose bin coordinate rounds up to exactly 8.0 goes
+    to des[8] instead of being dropped.  A float ramp with a minute vertical slope and keypoints of
+    orientation 0 makes (0 - theta)*4/pi + 8 round to 8.0 for most samples, so the two modes differ."""
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = (xx / w + 1e-7 * yy / h + 0.05 * np.sin(xx * 0.9) * np.sin(yy * 0.7)).astype(np.float32)
+    keys = np.zeros(6, dtype=_abi.KEYPOINT_DTYPE)
+    keys["x"] = [30, 50, 64, 80, 100, 64]; keys["y"] = [30, 48, 40, 60, 50, 70]
+    keys["s"] = [2.0, 3.0, 2.5, 4.0, 2.2, 6.0]; keys["o"] = 0.0
+    out = {}
+    for di in (0, 1):
+        g, o = _pair(gpu_ctx_factory, dynamic_indexing=di)
+        g.run(img[None]); o.run(img[None])
+        assert g.run_keypoints(keys, 1) == o.run_keypoints(keys, 1) == len(keys)
+        _same(g, o, f"dynamic_indexing={di}")
+        out[di] = g.fetch(0)[1].copy()
+    # keypoint angle float(2*pi) on ramps whose gradient direction is 0 (or a few 1e-7 rad): the kernel's
+    # angle is then a hair below the pixel's, (angle - theta)*4/pi is within half an ulp below 0 and
+    # "+ 8" rounds to exactly 8.0 for (nearly) every sample: dropped without -di, added to des[8] with it
+    differs = 0
+    keys["o"] = np.float32(6.2831855)
+    for slope in (0.0, 2.0e-7, 1.0e-6):
+        img2 = (xx.astype(np.float64) / w + slope * yy.astype(np.float64) / h).astype(np.float32)
+        res = {}
+        for di in (0, 1):
+            g, o = _pair(gpu_ctx_factory, dynamic_indexing=di, normalize=0)
+            g.run(img2[None]); o.run(img2[None])
+            g.run_keypoints(keys, 1); o.run_keypoints(keys, 1)
+            _same(g, o, f"ramp {slope}, dynamic_indexing={di}")
+            res[di] = g.fetch(0)[1].copy()
+        differs += int(not np.array_equal(res[0], res[1]))
+    out[10], out[11] = (0, 1) if differs == 3 else (0, 0)
+    assert not np.array_equal(out[10], out[11]), "the -di path was not exercised"
+
+
 def test_keypoint_list_errors(gpu_ctx_factory):
     from hessgpu_amd.session import HessError
 

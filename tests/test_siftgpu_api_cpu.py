@@ -40,6 +40,7 @@ def test_value_options():
 
 
 def test_out_of_range_values_are_ignored():
+    assert _params([]).dynamic_indexing == 0 and _params(["-di"]).dynamic_indexing == 1  # SiftGPU.cpp:1030
     p = _params(["-t", "0.7", "-e", "-1", "-d", "11", "-fo", "-1", "-topk", "0"])
     assert abs(p.dog_threshold - 0.02 / 3) < 1e-9 and p.edge_threshold == 10.0 and p.dog_level_num == 3
     assert p.first_octave == 0
