@@ -11,7 +11,10 @@
  * GLEW/GLUT/DevIL).  This oracle is therefore a plain-C restatement of the reference's
  * algorithm, checked only against (a) IEEE facts it must satisfy (half conversions vs
  * numpy.float16, math functions vs libm), and (b) an independently written NumPy
- * restatement (tests/np_restatement.py).
+ * restatement (tests/np_restatement.py), and (c) for the stages shared with the DoG build of the family
+ * (pyramid, gradient planes, descriptor, normalisation, SaveSIFT quantisation) against the reference's one
+ * shipped feature file doc/evaluation/box.siftgpu through the user-keypoint entry point
+ * (tests/test_reference_fixture.py: 42 % of the comparable keypoints within 2 counts of 512 in all values).
  *
  * Same entry points as include/hess_abi.h with the prefix hess_cpu_.
  */
