@@ -870,7 +870,8 @@ void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, 
                          const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
   (void)gauss;
   (void)hipMemsetAsync(rowcnt, 0, (size_t)batch * g.NR * sizeof(int), st);
-  if (g.dog <= 5) {  // streaming scan; sets mask bits with atomics
+  // streaming scan (sets mask bits with atomics); its candidate queue packs row and column in 14 bits each
+  if (g.dog <= 5 && g.o[0].wa < (1 << 14) && g.o[0].h < (1 << 14)) {
     (void)hipMemsetAsync(rowmask, 0, (size_t)batch * g.NM * sizeof(uint64_t), st);
     unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);
     const dim3 grid(g.nstream, batch), blk(256);
@@ -883,7 +884,8 @@ void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, 
     }
     return;
   }
-  // more than 5 detection levels per octave: LDS-tiled scan (level count is a run-time value there)
+  // more than 5 detection levels per octave, or planes of 16384 px and more: LDS-tiled scan (level count
+  // and plane size are run-time values there)
   const size_t lds = (size_t)(g.dog + 2) * (EX_TR + 2) * EX_STRIDE * sizeof(float);
   static size_t lds_allowed = 0;  // dog >= 4 needs more than the default 64 KB of dynamic LDS
   if (lds > lds_allowed) {
