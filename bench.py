@@ -243,7 +243,17 @@ def cpu_baseline(sample_imgs):
             break
     dt = time.perf_counter() - t0
     o.close()
+    # single-thread figure (SURVEY 8d asks for both): two images, about 2 s
+    o1 = OracleSession(threads=1, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK)
+    t1 = time.perf_counter()
+    n1 = 0
+    for i in range(min(2, len(sample_imgs))):
+        o1.run(sample_imgs[i:i + 1])
+        n1 += 1
+    dt1 = time.perf_counter() - t1
+    o1.close()
     return {
+        "value_single_thread": round(n1 * W * H / dt1 / 1e6, 2),
         "value": round(n * W * H / dt / 1e6, 2),
         "unit": "Mpix/s",
         "cores": cores,
