@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images per GPU (tiled to --batch)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) pipelined per GPU")
