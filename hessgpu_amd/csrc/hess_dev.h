@@ -35,7 +35,7 @@ struct OctGeom {
   long long got_off;    // element offset of [octave][1][0] in got (units: float2)
   int row_base;         // first row index of this octave in the per-image row order
   int mask_base;        // first mask word of this octave in the per-image mask array
-  int tiles_x;          // extrema tiles (256 x 8 px) per row of tiles
+  int tiles_x;          // LDS-tiled extrema scan: 128 x 4 px tiles per row of tiles
   int tile_base;        // first extrema tile of this octave in the per-image tile order
   int strips;           // streaming extrema scan: 124-column strips per row (k_detect.hip)
   int stream_base;      // first streaming workgroup of this octave in the per-image order

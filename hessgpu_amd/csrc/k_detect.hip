@@ -6,12 +6,16 @@
 // and the bitonic-sort/Blelloch top-K chain (:2205-3051).
 //
 // Structure (no key map, no atomics on the list, no host round trip):
-//   extrema_mark   one wavefront per image row: 64 pixels per step, __ballot -> one 64-bit mask
-//                  word per step and a row count;
+//   hessian_rows4  det-H of the octave's top level (the other levels come fused out of the Gaussian
+//                  launches, k_gauss.hip); hessian_kernel is the general one-row form (det-H + gradient);
+//   extrema_stream pass 1 (dog <= 5): register-streaming 26-neighbour scan, candidates queued for the
+//                  reference's exact test, positional mask bits + row counts (extrema_mark: LDS-tiled
+//                  variant for larger level counts / planes);
 //   row_scan       one workgroup per image: exclusive scan of the row counts in list order
 //                  (level, row) -> row offsets, level totals, -tc level truncation;
-//   extrema_scatter one wavefront per row: lanes whose mask bit is set recompute their keypoint
-//                  and write it at row offset + popcount(lower bits): row-major, deterministic;
+//   extrema_scatter pass 2, one thread per detection: row by binary search in the offsets, column = k-th
+//                  set bit of the row's mask words, keypoint recomputed, written at its list position:
+//                  (level,row,col) order, deterministic;
 //   topk           15-bit histogram of abs(half(response)) -> exact cut, then one ordered
 //                  compaction pass (ties at the cut resolved towards the lower list index).
 #include "hess_dev.h"
