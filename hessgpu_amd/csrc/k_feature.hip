@@ -6,12 +6,16 @@
 // ComputeDescriptor_Kernel (16 threads per keypoint, ProgramCU.cu:1650-1804) and
 // NormalizeDescriptor_Kernel (ProgramCU.cu:1950-2054).
 //
-// One 64-lane wavefront per keypoint (orientation) / per feature (descriptor).  Samples are
-// evaluated 64 at a time (one per lane: address, window test, expf weight); the histogram bins
-// live one per lane, and each bin receives its contributions in the reference's sample order
-// (row-major over the window), so sums are bit-identical to a sequential scan: the contributing
-// lanes are visited in ascending order through v_readlane broadcasts and only the lane that owns
-// the addressed bin performs the fmaf.
+// One 64-lane wavefront per keypoint (orientation) / per feature (descriptor); every histogram bin
+// receives its contributions in the reference's sample order (row-major over the window), so sums are
+// bit-identical to a sequential scan.
+//   orientation  64 window samples per step, one per lane, branch-free; the samples inside the disc are
+//                compacted in order into an LDS record list; lane j (bin j) reads every record by LDS
+//                broadcast and adds it with coefficient (bin == j ? gradient : 0);
+//   descriptor   lane = cell*4 + q: the four lanes of a cell take four consecutive samples of the cell's
+//                box per iteration, hits are appended in order to the cell's LDS list, and lane (cell, q)
+//                owns bins q, q+4 (q = 0 also 8) of its cell and walks the list (see descriptor_kernel).
+// Built without the SLP vectoriser (hessgpu_amd/build.py): packed FP32 issues at half rate on gfx950.
 #include "hess_dev.h"
 #include "hess_devmath.h"
 

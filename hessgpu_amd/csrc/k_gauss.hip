@@ -2,11 +2,14 @@
 //
 // Replaces FilterH<FW>/FilterV<FW> (two global passes through a scratch buffer, ProgramCU.cu:117-231,
 // 455-512), DownsampleKernel (ProgramCU.cu:312-326) and the host-side pixel conversion
-// (GLTexImage.cpp:802-916).  HBM-bound: 4 B read + 4 B written per pixel and level.
+// (GLTexImage.cpp:802-916).  By bytes HBM-bound (4 B read + 4 B written per pixel and level, + 4/12 B for
+// the fused planes); measured, vector-ALU issue is the contended resource.
 //
 // gauss_kernel: one workgroup (256 threads = 4 wavefronts) produces a 64x32 tile of one level.
 //   stage 1  source rows [y0-R, y0+32+R) x cols [x0-R4, x0+64+R4) -> LDS `s`, 16-byte global loads,
 //            borders replicated exactly as the reference clamps its fetch index;
+//   stage 1b (HESS) det-Hessian*sigma^4 and (gradient/2, theta) of the SOURCE level from the staged window,
+//            in the same launch (ComputeHessian_Kernel, ProgramCU.cu:523-595): the level is not re-read;
 //   stage 2  horizontal pass LDS->LDS: a thread produces 8 adjacent outputs from a register window
 //            (ds_read_b128, row stride = 4 mod 8 dwords: conflict-free);
 //   stage 3  vertical pass LDS->HBM: a thread produces 4 rows x 2 columns (ds_read_b64, 8-byte
