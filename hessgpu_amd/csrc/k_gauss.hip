@@ -49,12 +49,10 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   constexpr int SW = TW + 2 * R4;
   constexpr int SWP = SW + 4;          // SW % 8 == 0 -> row stride = 4 (mod 8) dwords
   constexpr int ROWS = TH + 2 * R;
-  constexpr int TWP = TW + 4;
   constexpr int NG = SW / 4;           // 16-byte groups per staged row
   constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
 
   __shared__ __attribute__((aligned(16))) float s[ROWS * SWP];
-  __shared__ __attribute__((aligned(16))) float t[ROWS * TWP];
 
   const int tid = threadIdx.x;
   const int w = a.w, h = a.h;
@@ -198,26 +196,44 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
     }
   }
 
-  // ---- stage 2: horizontal pass, LDS -> LDS ----
-  for (int task = tid; task < ROWS * (TW / 8); task += NT) {
-    int r = task >> 3, xb = (task & 7) * 8;
-    float win[NV * 4];
+  // ---- stage 2: horizontal pass, LDS -> LDS in place ----
+  // Every thread first computes its (at most two) 8-output tasks from the source window into registers;
+  // after a barrier (all windows read) the results overwrite columns 0..63 of their row.  One LDS array
+  // instead of two: 15-26 KB per workgroup, so registers (7 wavefronts per SIMD), not LDS (5), bound occupancy.
+  {
+    constexpr int NTASK = (ROWS * (TW / 8) + NT - 1) / NT;
+    float acc[NTASK][8];
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      float4 q = *reinterpret_cast<const float4*>(&s[r * SWP + xb + 4 * i]);
-      win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
+    for (int k = 0; k < NTASK; k++) {
+      const int task = tid + k * NT;
+      if (task < ROWS * (TW / 8)) {
+        const int r = task >> 3, xb = (task & 7) * 8;
+        float win[NV * 4];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+          float4 q = *reinterpret_cast<const float4*>(&s[r * SWP + xb + 4 * i]);
+          win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[k][j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FW; i++) {
+          const float ki = a.taps.k[i];
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[k][j] = fmaf(win[OFF + j + i], ki, acc[k][j]);  // ProgramCU.cu:152
+        }
+      }
     }
-    float acc[8];
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < FW; i++) {
-      const float ki = a.taps.k[i];
-#pragma unroll
-      for (int j = 0; j < 8; j++) acc[j] = fmaf(win[OFF + j + i], ki, acc[j]);  // ProgramCU.cu:152
+    for (int k = 0; k < NTASK; k++) {
+      const int task = tid + k * NT;
+      if (task < ROWS * (TW / 8)) {
+        const int r = task >> 3, xb = (task & 7) * 8;
+        *reinterpret_cast<float4*>(&s[r * SWP + xb]) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        *reinterpret_cast<float4*>(&s[r * SWP + xb + 4]) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+      }
     }
-    *reinterpret_cast<float4*>(&t[r * TWP + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4*>(&t[r * TWP + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
   __syncthreads();
 
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
     float2 col[4 + 2 * R];
 #pragma unroll
     for (int i = 0; i < 4 + 2 * R; i++)
-      col[i] = *reinterpret_cast<const float2*>(&t[(rg * 4 + i) * TWP + cg * 2]);
+      col[i] = *reinterpret_cast<const float2*>(&s[(rg * 4 + i) * SWP + cg * 2]);
     float2 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[j] = make_float2(0.0f, 0.0f);
