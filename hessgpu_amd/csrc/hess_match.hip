@@ -3,20 +3,22 @@
 // Replaces SiftMatchCU (SiftMatchCU.cpp:71-176) and its kernels MultiplyDescriptor(_G)_Kernel,
 // RowMatch_Kernel, ColMatch_Kernel (ProgramCU.cu:3455-3843).  Integer work: results are bit-exact.
 //
-//   match_dot_kernel   64x64 tile of the num1 x num2 dot-product matrix per workgroup; both 8 KB
-//                      descriptor panels staged in LDS, 4x4 outputs per thread, v_dot4_u32_u8 over the
-//                      128-byte descriptors (the only dense contraction in the tree; at 4096 x 4096 it is
-//                      2.1 GMAC, far below what would need MFMA); guided mode applies the reference's
-//                      homography / fundamental-matrix gates per pair and its per-8-row-block rule;
-//   match_row_kernel   one wavefront per row: best / second best with the reference's tie order (its
-//                      32-thread tree: partners 16, 8, 4, 2, 1 apart, ties keep the lower thread), acos
-//                      distance + ratio test;
-//   match_col_kernel   one thread per column merges the per-tile (max, index, second) partials that the
-//                      dot kernel's epilogue produced, in ascending row order.
+// Unguided match (GetSiftMatch): matrix cores, no score matrix in memory --
+//   match_mfma_kernel      one wavefront per (32-row block, column segment): v_mfma_i32_32x32x32_i8 tiles whose
+//                          C layout (column on the lane, 16 rows in registers) makes RowMatch_Kernel's 32 strided
+//                          thread scans and the column partials per-lane folds; see the comment at the kernel;
+//   match_rowmerge_kernel  merges the per-segment thread states in column order, then the reference's 32-thread
+//                          tree (partners 16, 8, 4, 2, 1 apart, ties keep the lower thread), acos distance + ratio;
+//   match_col_kernel       merges the per-row-block (max, index, second) column partials in ascending row order.
+// Guided match (GetGuidedSiftMatch: per-pair homography / fundamental-matrix gates, per-8-row-block rule) --
+//   match_dot_kernel       64x64 tile of the dot-product matrix per workgroup, descriptor panels in LDS,
+//                          v_dot4_u32_u8, gates per pair, score matrix written for
+//   match_row_kernel       one wavefront per row over the matrix (same tie order), and match_col_kernel.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -180,18 +182,156 @@ __global__ __launch_bounds__(256) void match_row_kernel(const int* dotm, int num
   if (lane == 0) rowm[row] = decide(mx, nx, ix, distmax, ratiomax);
 }
 
-// ColMatch_Kernel (ProgramCU.cu:3808-3827): merge the row-tile partials of a column in ascending order.
+// ColMatch_Kernel (ProgramCU.cu:3808-3827): merge the row-block partials of a column in ascending row order.
+// The merge is associative (ties go to the earlier rows), so a column's partials are split into 8 consecutive
+// chunks folded by 8 threads and combined in chunk order: 32 columns x 8 chunks per workgroup.
 __global__ __launch_bounds__(256) void match_col_kernel(const int3* cpart, int ntile, int num2, float distmax,
                                                         float ratiomax, int* colm) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= num2) return;
-  int3 t = cpart[j];
-  for (int q = 1; q < ntile; q++) {
-    const int3 u = cpart[(size_t)q * num2 + j];
-    if (t.x < u.x) t = make_int3(u.x, u.y, max(t.x, u.z));
-    else t.z = max(t.z, u.x);
+  __shared__ int3 part[8][32];
+  const int c = threadIdx.x & 31, ch = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  const int per = (ntile + 7) >> 3;
+  const int q0 = ch * per, q1 = min(q0 + per, ntile);
+  int3 t = make_int3(0, -1, 0);  // neutral: the per-block partials start from the same state
+  if (j < num2)
+    for (int q = q0; q < q1; q++) {
+      const int3 u = cpart[(size_t)q * num2 + j];
+      if (t.x < u.x) t = make_int3(u.x, u.y, max(t.x, u.z));
+      else t.z = max(t.z, u.x);
+    }
+  part[ch][c] = t;
+  __syncthreads();
+  if (ch == 0 && j < num2) {
+    for (int k = 1; k < 8; k++) {
+      const int3 u = part[k][c];
+      if (t.x < u.x) t = make_int3(u.x, u.y, max(t.x, u.z));
+      else t.z = max(t.z, u.x);
+    }
+    colm[j] = decide(t.x, t.z, t.y, distmax, ratiomax);
   }
-  colm[j] = decide(t.x, t.z, t.y, distmax, ratiomax);
+}
+
+// ---- unguided match on the matrix cores -----------------------------------------------------------------
+// The num1 x num2 dot products are never written out.  One wavefront owns a block of 32 rows and a segment
+// of the columns and walks the segment in 32-column tiles: 4 x v_mfma_i32_32x32x32_i8 per tile (A fragments =
+// the block's 32 descriptors, resident in registers; B fragments = 32 descriptors of set 2, 16-byte loads
+// straight from L2, no LDS).  The C layout puts column j0 + (lane & 31) on the lane and 16 rows in its
+// registers, and a tile aligned to 32 columns holds exactly one element of each of RowMatch_Kernel's 32
+// strided threads (class = j mod 32 = lane & 31): the per-thread scan of the reference (strict '>' keeps
+// the first maximum, second = second largest) is a per-lane fold over the tiles with no cross-lane traffic.
+// Column partials (max, index, second over the block's rows in ascending order, ColMatch's merge rule) are
+// folded per lane over the registers and merged once across the two lane halves.
+// Descriptors are unsigned bytes, the instruction multiplies signed ones: bytes are biased by -128 (xor 0x80)
+// and the exact dot product is restored as dot_s + 128 (sum a + sum b) - 128^2 * 128 from per-descriptor sums.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void col_merge(int3& a, const int3& b) {  // a: earlier rows, b: later rows
+  if (a.x < b.x) a = make_int3(b.x, b.y, max(a.x, b.z));
+  else a.z = max(a.z, b.x);
+}
+
+__global__ __launch_bounds__(256) void match_mfma_kernel(const uint8_t* des1, int num1, const uint8_t* des2, int num2,
+                                                         const int* rfix, const int* cfix, int nseg, int tiles_per_seg,
+                                                         int3* cpart, int3* rstate) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = blockIdx.x, sg = blockIdx.y * 4 + wv;
+  if (sg >= nseg) return;  // wavefront-uniform; no workgroup barrier in this kernel
+  const int i0 = rb * 32;
+  const int ntile2 = (num2 + 31) >> 5;
+  v4i a[4];
+  {
+    // hardware row r of the tile carries descriptor row i0 + perm(r), chosen so that the 16 accumulator
+    // registers of a lane are 16 CONSECUTIVE descriptor rows (i0 + reg + 16 h): the column partial of a
+    // lane is then a plain in-order fold and the two lane halves merge once per tile
+    const int prow = (r & 3) + 4 * (r >> 3) + 16 * ((r >> 2) & 1);
+    const uint8_t* pa = des1 + (size_t)min(i0 + prow, num1 - 1) * KD + 16 * h;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) a[kk] = *reinterpret_cast<const v4i*>(pa + kk * 32) ^ (int)0x80808080;
+  }
+  int ra[16], mx[16], nx[16], ix[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    const int row = i0 + reg + 16 * h;
+    ra[reg] = row < num1 ? rfix[row] : -(1 << 29);  // rows past the end: far below every real score, no overflow
+    mx[reg] = 0; nx[reg] = 0; ix[reg] = -1;          // RowMatch_Kernel's initial state, ProgramCU.cu:3745-3747
+  }
+  const int t1 = min((sg + 1) * tiles_per_seg, ntile2);
+  auto load_b = [&](int t, v4i (&b)[4], int& cbv) {  // B fragments + column offset of tile t (clamped past the end)
+    const int jj = t * 32 + r;
+    const int jc = min(jj, num2 - 1);
+    const uint8_t* pb = des2 + (size_t)jc * KD + 16 * h;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) b[kk] = *reinterpret_cast<const v4i*>(pb + kk * 32);
+    cbv = jj < num2 ? cfix[jc] : -(1 << 29);  // columns past the end: far below every real score
+  };
+  v4i bn[4];
+  int cbn;
+  load_b(sg * tiles_per_seg, bn, cbn);
+  for (int t = sg * tiles_per_seg; t < t1; t++) {
+    const int j = t * 32 + r;
+    v4i b[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) b[kk] = bn[kk] ^ (int)0x80808080;
+    const int cb = cbn;
+    load_b(min(t + 1, ntile2 - 1), bn, cbn);  // next tile's loads fly while this tile is reduced
+    v16i c = {0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk], b[kk], c, 0, 0, 0);
+    int cx = 0, cy = -1, cz = 0;  // column partial over this lane's 16 rows (ProgramCU.cu:3510-3519)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int v = c[reg] + ra[reg] + cb;                     // invalid row/column: far below 0
+      // RowMatch_Kernel's thread update (ProgramCU.cu:3756-3760); second = median(max, v, second)
+      nx[reg] = max(min(mx[reg], v), nx[reg]);
+      ix[reg] = (v > mx[reg]) ? j : ix[reg];
+      mx[reg] = max(mx[reg], v);
+      if (cpart) {
+        cz = max(min(cx, v), cz);
+        cy = (v > cx) ? i0 + reg + 16 * h : cy;
+        cx = max(cx, v);
+      }
+    }
+    if (cpart) {  // rows of lane half 0 precede those of half 1
+      const int ox = __shfl_xor(cx, 32), oy = __shfl_xor(cy, 32), oz = __shfl_xor(cz, 32);
+      int3 lo = h ? make_int3(ox, oy, oz) : make_int3(cx, cy, cz);
+      const int3 hi = h ? make_int3(cx, cy, cz) : make_int3(ox, oy, oz);
+      col_merge(lo, hi);
+      if (h == 0 && j < num2) cpart[(size_t)rb * num2 + j] = lo;
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    const int row = i0 + reg + 16 * h;
+    if (row < num1) rstate[((size_t)row * nseg + sg) * 32 + r] = make_int3(mx[reg], nx[reg], ix[reg]);
+  }
+}
+
+// Rows: merge the per-segment thread states of each of the 32 strided threads in column order (a later
+// segment only wins with a strictly larger maximum), then the reference's tree over the 32 threads.
+__global__ __launch_bounds__(256) void match_rowmerge_kernel(const int3* rstate, int num1, int nseg, float distmax,
+                                                             float ratiomax, int* rowm) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+  const int rowc = min(row, num1 - 1);  // keep every lane in the shuffles below
+  const int3* p = rstate + (size_t)rowc * nseg * 32 + t;
+  int3 s = p[0];
+  for (int q = 1; q < nseg; q++) {
+    const int3 u = p[(size_t)q * 32];
+    if (u.x > s.x) s = make_int3(u.x, max(s.x, u.y), u.z);
+    else s.y = max(s.y, u.x);
+  }
+  int mx = s.x, nx = s.y, ix = s.z;
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {  // ProgramCU.cu:3766-3780: partner d away, a tie keeps the lower thread
+    const int omx = __shfl_down(mx, d, 32), onx = __shfl_down(nx, d, 32), oix = __shfl_down(ix, d, 32);
+    const bool take = omx > mx;
+    const int nnx = take ? max(mx, onx) : max(nx, omx);
+    ix = take ? oix : ix;
+    mx = take ? omx : mx;
+    nx = nnx;
+  }
+  if (t == 0 && row < num1) rowm[row] = decide(mx, nx, ix, distmax, ratiomax);
 }
 
 }  // namespace
@@ -205,6 +345,11 @@ struct hess_matcher {
   int3* cpart = nullptr;
   int *dotm = nullptr, *rowm = nullptr, *colm = nullptr;
   size_t mat_cap = 0;
+  // matrix-core path (unguided): per-descriptor byte sums turned into score offsets, per-segment row states
+  int* fix[2] = {nullptr, nullptr};
+  int3 *cpart2 = nullptr, *rstate = nullptr;
+  size_t cpart2_cap = 0, rstate_cap = 0;
+  int rc_cap = 0;
   std::vector<int> hrow, hcol;
   std::string err;
   float last_ms = 0.0f;
@@ -246,6 +391,7 @@ void hess_matcher_destroy(hess_matcher* m) {
   (void)hipSetDevice(m->device);
   for (int k = 0; k < 2; k++) { (void)hipFree(m->des[k]); (void)hipFree(m->loc[k]); }
   (void)hipFree(m->cpart); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
+  (void)hipFree(m->fix[0]); (void)hipFree(m->fix[1]); (void)hipFree(m->cpart2); (void)hipFree(m->rstate);
   if (m->e0) (void)hipEventDestroy(m->e0);
   if (m->e1) (void)hipEventDestroy(m->e1);
   if (m->st) (void)hipStreamDestroy(m->st);
@@ -268,9 +414,20 @@ int hess_matcher_set_descriptors(hess_matcher* m, int index, int num, const unsi
   (void)hipFree(m->des[index]);
   m->des[index] = nullptr;
   m->num[index] = num;
+  (void)hipFree(m->fix[index]);
+  m->fix[index] = nullptr;
   if (num) {
     M_TRY(m, hipMalloc(&m->des[index], (size_t)num * KD));
     M_TRY(m, hipMemcpy(m->des[index], des, (size_t)num * KD, hipMemcpyHostToDevice));
+    // score offsets of the matrix-core path: rows 128*sum - 128^2*128, columns 128*sum (see match_mfma_kernel)
+    std::vector<int> f((size_t)num);
+    for (int i = 0; i < num; i++) {
+      int sum = 0;
+      for (int k = 0; k < KD; k++) sum += des[(size_t)i * KD + k];
+      f[i] = 128 * sum - (index == 0 ? 128 * 128 * KD : 0);
+    }
+    M_TRY(m, hipMalloc(&m->fix[index], (size_t)num * sizeof(int)));
+    M_TRY(m, hipMemcpy(m->fix[index], f.data(), (size_t)num * sizeof(int), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -311,29 +468,63 @@ int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* 
   if (guided && (!H || !F)) { m->err = "guided matching needs both H and F"; return HESS_ERR_ARG; }
   if (guided && (!m->have_loc[0] || !m->have_loc[1])) return 0;  // SiftMatchCU.cpp:131
   M_TRY(m, hipSetDevice(m->device));
-  const size_t need = (size_t)n1 * n2;
-  if (need > m->mat_cap) {
-    (void)hipFree(m->cpart); (void)hipFree(m->dotm); (void)hipFree(m->rowm); (void)hipFree(m->colm);
-    m->cpart = nullptr;
-    m->dotm = m->rowm = m->colm = nullptr;
-    M_TRY(m, hipMalloc(&m->cpart, (size_t)((m->max_sift + TM - 1) / TM + 1) * m->max_sift * sizeof(int3)));
-    M_TRY(m, hipMalloc(&m->dotm, need * sizeof(int)));
+  if (m->rc_cap < m->max_sift) {
+    (void)hipFree(m->rowm); (void)hipFree(m->colm);
+    m->rowm = m->colm = nullptr;
     M_TRY(m, hipMalloc(&m->rowm, (size_t)m->max_sift * sizeof(int) + 4));
     M_TRY(m, hipMalloc(&m->colm, (size_t)m->max_sift * sizeof(int) + 4));
+    m->rc_cap = m->max_sift;
+  }
+  if (!guided) {
+    // matrix-core path: enough (row block, column segment) wavefronts to fill the chip
+    const int nrb = (n1 + 31) / 32, ntile2 = (n2 + 31) / 32;
+    static const int target_waves = getenv("HESS_MATCH_WAVES") ? atoi(getenv("HESS_MATCH_WAVES")) : 2048;
+    int nseg = (target_waves + nrb - 1) / nrb;
+    nseg = nseg < 1 ? 1 : (nseg > ntile2 ? ntile2 : nseg);
+    const int tiles_per_seg = (ntile2 + nseg - 1) / nseg;
+    nseg = (ntile2 + tiles_per_seg - 1) / tiles_per_seg;
+    const size_t need_rs = (size_t)n1 * nseg * 32, need_cp = (size_t)nrb * n2;
+    if (need_rs > m->rstate_cap) {
+      (void)hipFree(m->rstate); m->rstate = nullptr;
+      M_TRY(m, hipMalloc(&m->rstate, need_rs * sizeof(int3)));
+      m->rstate_cap = need_rs;
+    }
+    if (mutual_best && need_cp > m->cpart2_cap) {
+      (void)hipFree(m->cpart2); m->cpart2 = nullptr;
+      M_TRY(m, hipMalloc(&m->cpart2, need_cp * sizeof(int3)));
+      m->cpart2_cap = need_cp;
+    }
+    (void)hipEventRecord(m->e0, m->st);
+    hipLaunchKernelGGL(match_mfma_kernel, dim3(nrb, (nseg + 3) / 4), dim3(256), 0, m->st, m->des[0], n1, m->des[1], n2,
+                       m->fix[0], m->fix[1], nseg, tiles_per_seg, mutual_best ? m->cpart2 : nullptr, m->rstate);
+    hipLaunchKernelGGL(match_rowmerge_kernel, dim3((n1 + 7) / 8), dim3(256), 0, m->st, m->rstate, n1, nseg, distmax,
+                       ratiomax, m->rowm);
+    if (mutual_best)
+      hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 31) / 32), dim3(256), 0, m->st, m->cpart2, nrb, n2, distmax,
+                         ratiomax, m->colm);
+  } else {
+  const size_t need = (size_t)n1 * n2;
+  if (need > m->mat_cap) {
+    (void)hipFree(m->cpart); (void)hipFree(m->dotm);
+    m->cpart = nullptr;
+    m->dotm = nullptr;
+    M_TRY(m, hipMalloc(&m->cpart, (size_t)((m->max_sift + TM - 1) / TM + 1) * m->max_sift * sizeof(int3)));
+    M_TRY(m, hipMalloc(&m->dotm, need * sizeof(int)));
     m->mat_cap = need;
   }
   GeoParams gp;
   memset(&gp, 0, sizeof(gp));
-  gp.guided = guided ? 1 : 0;
-  if (guided) { memcpy(gp.H, H, 36); memcpy(gp.F, F, 36); gp.hdistmax = hdistmax; gp.fdistmax = fdistmax; }
+  gp.guided = 1;
+  memcpy(gp.H, H, 36); memcpy(gp.F, F, 36); gp.hdistmax = hdistmax; gp.fdistmax = fdistmax;
   (void)hipEventRecord(m->e0, m->st);
   hipLaunchKernelGGL(match_dot_kernel, dim3((n2 + TN - 1) / TN, (n1 + TM - 1) / TM), dim3(256), 0, m->st, m->des[0], n1,
                      m->des[1], n2, m->loc[0], m->loc[1], gp, mutual_best ? m->cpart : nullptr, m->dotm);
   hipLaunchKernelGGL(match_row_kernel, dim3((n1 + 3) / 4), dim3(256), 0, m->st, m->dotm, n1, n2, distmax, ratiomax,
                      m->rowm);
   if (mutual_best)
-    hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 255) / 256), dim3(256), 0, m->st, m->cpart, (n1 + TM - 1) / TM, n2,
+    hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 31) / 32), dim3(256), 0, m->st, m->cpart, (n1 + TM - 1) / TM, n2,
                        distmax, ratiomax, m->colm);
+  }
   (void)hipEventRecord(m->e1, m->st);
   m->hrow.resize(n1);
   m->hcol.resize(n2);

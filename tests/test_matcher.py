@@ -119,6 +119,33 @@ def test_gpu_matcher_bit_exact_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_matcher_full_byte_range_sizes_and_ties():
+    """The unguided match runs on the matrix cores with signed bytes (bias 128 + exact correction), 32-row
+    blocks and column segments: full-range unsigned bytes, sizes around the block/segment boundaries and
+    heavy ties (duplicated descriptors in different segments and strided-thread classes)."""
+    from hessgpu_amd.matcher import Matcher
+
+    rng = np.random.RandomState(7)
+    m = Matcher(0, max_sift=8192)
+    for n1, n2 in ((1, 5), (33, 31), (32, 32), (257, 1025), (1500, 3100)):
+        a = rng.randint(0, 256, size=(n1, 128)).astype(np.uint8)
+        b = rng.randint(0, 256, size=(n2, 128)).astype(np.uint8)
+        # duplicates: rows of b copied far apart (ties on rows), rows of a copied (ties on columns)
+        if n2 > 8:
+            b[n2 // 2] = b[3]; b[n2 - 1] = b[3]; b[(n2 // 2) ^ 1] = b[5]
+            if n1 > 8:
+                b[7] = a[2]; b[n2 - 2] = a[2]; a[n1 - 1] = a[2]; a[n1 // 2] = a[4]
+        m.set_descriptors(0, a)
+        m.set_descriptors(1, b)
+        for mutual in (True, False):
+            for dm, rm in ((2.0, 2.0), (0.9, 0.9)):
+                got = m.match(distmax=dm, ratiomax=rm, mutual_best=mutual)
+                ref = oracle_match(a, b, distmax=dm, ratiomax=rm, mutual_best=mutual)
+                assert np.array_equal(got, ref), (n1, n2, mutual, dm, rm)
+    m.close()
+
+
+@pytest.mark.gpu
 def test_siftmatchgpu_class_through_the_c_mirror():
     import ctypes as C
 

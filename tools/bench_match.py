@@ -28,9 +28,9 @@ def main():
             m.match(max_match=n)
             ts.append(m.last_ms())
         ms = float(np.median(ts))
-        traffic = n * n * 4 * 2  # score matrix written once, read once by the row pass (column partials are small)
         out = {"n1": n, "n2": n, "device_ms": round(ms, 4), "GMAC_per_s": round(n * n * 128 / ms / 1e6, 1),
-               "algorithmic_GB_per_s": round(traffic / ms / 1e6, 1), "bound": "hbm (int32 score matrix)"}
+               "path": "unguided: v_mfma_i32_32x32x32_i8 tiles, row/column reductions folded in registers, "
+                       "no score matrix in memory"}
         if n == 1024:
             from oracle_lib import oracle_match
 
