@@ -127,7 +127,8 @@ def test_gpu_matcher_full_byte_range_sizes_and_ties():
 
     rng = np.random.RandomState(7)
     m = Matcher(0, max_sift=8192)
-    for n1, n2 in ((1, 5), (33, 31), (32, 32), (257, 1025), (1500, 3100)):
+    # above 3 Mi pairs the matrix-core path runs, below it the one-pass dot kernel
+    for n1, n2 in ((1, 5), (33, 31), (32, 32), (257, 1025), (1500, 3100), (2049, 2081), (97, 40000 // 1)):
         a = rng.randint(0, 256, size=(n1, 128)).astype(np.uint8)
         b = rng.randint(0, 256, size=(n2, 128)).astype(np.uint8)
         # duplicates: rows of b copied far apart (ties on rows), rows of a copied (ties on columns)

@@ -29,8 +29,8 @@ def main():
             ts.append(m.last_ms())
         ms = float(np.median(ts))
         out = {"n1": n, "n2": n, "device_ms": round(ms, 4), "GMAC_per_s": round(n * n * 128 / ms / 1e6, 1),
-               "path": "unguided: v_mfma_i32_32x32x32_i8 tiles, row/column reductions folded in registers, "
-                       "no score matrix in memory"}
+               "path": ("unguided: v_mfma_i32_32x32x32_i8 tiles, row/column reductions folded in registers, no score "
+                        "matrix in memory") if n * n > (3 << 20) else "unguided, small: one-pass v_dot4 tiles + score matrix"}
         if n == 1024:
             from oracle_lib import oracle_match
 
