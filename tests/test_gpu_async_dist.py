@@ -71,3 +71,41 @@ def test_device_results_are_packed_and_gather_over_nccl(gpu_ctx_factory):
     finally:
         hdist._count_group.clear()
         dist.destroy_process_group()
+
+
+def test_one_context_per_host_thread(gpu_ctx_factory):
+    """MultiThreadSIFT.cpp's usage: one instance per host thread, RunSIFT concurrently.  Contexts share
+    nothing (own stream, buffers, parameters); results must equal the single-threaded ones."""
+    import threading
+
+    from oracle_lib import OracleSession
+
+    names = fixtures.list640()[:4]
+    imgs = [fixtures.load_rgb(n) for n in names]
+    ref = []
+    o = OracleSession(threads=8, keep_levels=False)
+    for im in imgs:
+        o.run(im[None])
+        ref.append(tuple(a.tobytes() for a in o.fetch(0)))
+    out, errs = {}, []
+
+    def work(tid):
+        try:
+            g = gpu_ctx_factory()
+            for rep in range(6):
+                for k in range(len(imgs)):
+                    i = (k + tid) % len(imgs)
+                    g.run(imgs[i][None])
+                    got = tuple(a.tobytes() for a in g.fetch(0))
+                    if got != ref[i]:
+                        errs.append((tid, rep, i))
+            out[tid] = True
+        except Exception as e:  # surfaces in the main thread's assert
+            errs.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and len(out) == 4, errs[:3]
