@@ -101,6 +101,8 @@ struct DescParams {
   float octave_sigma;   // 2^ds (PyramidCU.cpp:746-748)
   int dog;
   int dynamic_indexing;  // -di: theta == 8.0 goes to des[8] (ProgramCU.cu:1755-1759) instead of being dropped
+  HostKeypoint* hkeys;   // optional pinned-host mirrors of the packed results (same indexing as keys/desc)
+  float* hdesc;
 };
 
 // ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------

@@ -81,6 +81,8 @@ struct hess_ctx {
   std::vector<int> counts;
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
+  // results written by the descriptor kernel straight into the pinned host buffers (no D2H pass after it)
+  bool host_direct = false, host_direct_allowed = true;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
   // user-supplied keypoint list (SiftPyramid::SetKeypointList): used by the next run, then cleared
   std::vector<hess_keypoint> user_keys;
@@ -343,6 +345,17 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->keys, (size_t)B * cap_feat * sizeof(HostKeypoint)))) return rc;
   if (c->dim && (rc = ensure(c, c->desc, (size_t)B * cap_feat * c->dim * 4))) return rc;
   if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 8) * 4, true))) return rc;
+  {
+    // The descriptor kernel can store its packed results into host memory as well (posted PCIe writes that
+    // overlap the kernel itself): then no device->host pass follows the kernels.  Only while the worst-case
+    // result size stays moderate: the pinned buffers must hold B * cap_feat records up front.
+    const size_t host_bytes = (size_t)B * cap_feat * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
+    c->host_direct = c->host_direct_allowed && host_bytes <= ((size_t)512 << 20);
+    if (c->host_direct) {
+      if ((rc = ensure(c, c->h_keys, (size_t)B * cap_feat * sizeof(HostKeypoint), true))) return rc;
+      if (c->dim && (rc = ensure(c, c->h_desc, (size_t)B * cap_feat * c->dim * 4, true))) return rc;
+    }
+  }
 
   c->g = g;
   c->ds = ds;
@@ -533,6 +546,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;  // PyramidCU.cpp:746-748
   dsp.dog = g.dog;
   dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
+  dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
+  dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   {
     ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
     launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
@@ -645,6 +660,8 @@ int enqueue_user(hess_ctx* c) {
   dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
   dsp.dog = g.dog;
   dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
+  dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
+  dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
@@ -699,7 +716,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
   const size_t total = c->offs[batch];
   if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
   if (c->dim && (rc = ensure(c, c->h_desc, (total ? total : 1) * c->dim * 4, true))) return rc;
-  if (total) {
+  if (total && !c->host_direct) {
     HIP_TRY(c, hipMemcpyAsync(c->h_keys.p, c->keys.p, total * sizeof(HostKeypoint), hipMemcpyDeviceToHost, c->st));
     if (c->dim)
       HIP_TRY(c, hipMemcpyAsync(c->h_desc.p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, c->st));
@@ -775,6 +792,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
     return nullptr;
   }
   for (int i = 0; i < 8; i++) (void)hipEventCreate(&c->ev[i]);
+  { const char* zc = getenv("HESS_HOST_DIRECT"); c->host_direct_allowed = !(zc && zc[0] == '0'); }
   c->have_ev = true;
   return c;
 }

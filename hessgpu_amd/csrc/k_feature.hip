@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
       hk.level = (uint16_t)li;
       hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
       keys[obase + oidx] = hk;
+      if (dp.hkeys) dp.hkeys[obase + oidx] = hk;
     }
     if (!desc) continue;
 
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         }
       }
       if (lane < 32) *reinterpret_cast<float2*>(dout + lane * 2) = v;
+      if (dp.hdesc && lane < 32) *reinterpret_cast<float2*>(dp.hdesc + (obase + oidx) * dim + lane * 2) = v;
     } else {
       float4 v = make_float4(0, 0, 0, 0);
       if (lane < 32) v = *reinterpret_cast<const float4*>(&dl[wv][lane * 4]);
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         }
       }
       if (lane < 32) *reinterpret_cast<float4*>(dout + lane * 4) = v;
+      if (dp.hdesc && lane < 32) *reinterpret_cast<float4*>(dp.hdesc + (obase + oidx) * dim + lane * 4) = v;
     }
   }
 }
