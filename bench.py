@@ -84,7 +84,7 @@ def main():
     imgs = np.concatenate([imgs] * ((B + nd - 1) // nd))[:B]
     d_imgs = torch.from_numpy(imgs).to(dev)  # [B,H,W] u8 resident in HBM
 
-    # Contexts used round-robin (three measured best on MI355X: 2 -> 10.2, 3 -> 11.1, 4 -> 9.8 Gpix/s):
+    # Contexts used round-robin (three measured best on MI355X: 1 -> 10.8, 2 -> 12.4, 3 -> 12.7, 4 -> 12.1 Gpix/s):
     # while one batch's results travel to the host (and, for N > 1,
     # are gathered over RCCL), the next batch's kernels already run on the other context's stream.
     nctx = max(1, args.contexts)
