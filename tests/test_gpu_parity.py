@@ -231,6 +231,20 @@ def test_parity_noise_ragged(gpu_ctx_factory, w, h):
     _compare_all(g, o, img, f"noise {w}x{h}")
 
 
+def test_result_delivery_by_copy(gpu_ctx_factory, monkeypatch):
+    """Results normally reach the host through stores of the descriptor kernel into pinned memory; when the
+    worst-case result size is too large for that (or HESS_HOST_DIRECT=0) a device->host copy follows the
+    kernels instead.  Same results either way."""
+    monkeypatch.setenv("HESS_HOST_DIRECT", "0")
+    imgs = np.stack([fixtures.load_rgb(n) for n in fixtures.list640()[:3]])
+    g = gpu_ctx_factory()
+    monkeypatch.delenv("HESS_HOST_DIRECT")
+    g2 = gpu_ctx_factory()
+    o = OracleSession(threads=8, keep_levels=False)
+    _compare_all(g, o, imgs, "copy delivery", stages=False)
+    _compare_all(g2, o, imgs, "direct delivery", stages=False)
+
+
 def test_edge_cases(gpu_ctx_factory):
     g = gpu_ctx_factory()
     o = OracleSession(threads=1)
