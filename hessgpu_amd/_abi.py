@@ -103,6 +103,7 @@ PROTOTYPES = {
     "geometry": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_int)]),
     "debug_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "debug_list": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_int]),
+    "debug_key_levels": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "timing": (_P(C.c_float), [_ctx]),
     "last_error": (C.c_char_p, [_ctx]),
 }

@@ -121,6 +121,10 @@ void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long 
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
                     long long img_stride, int ds, float* dst, int w, int h, int batch);
 
+// Linear up-sampling by 2^log_scale of the converted input (UpsampleKernel, ProgramCU.cu:233-310); only for
+// an up-sampled first octave (first_octave < 0 through the C ABI).  src: [batch][h][w], dst: [batch][h<<k][w<<k].
+void launch_upsample(hipStream_t st, const float* src, int w, int h, int log_scale, float* dst, int batch);
+
 // Nearest decimation to the next octave (DownsampleKernel, ProgramCU.cu:312-326).
 void launch_downsample(hipStream_t st, const float* src, int sw, int splane, float* dst, int dw,
                        int dh, int batch);

@@ -74,7 +74,7 @@ struct hess_ctx {
   bool use_topk = false, multi = false;
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
-  DevBuf gauss, deth, got, input_f32, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
+  DevBuf gauss, deth, got, input_f32, upsampled, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
       hist, sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
   // host results
   int batch = 0;
@@ -89,6 +89,7 @@ struct hess_ctx {
   bool user_have_orientation = false;
   bool user_on_current = false;     // RunSIFT(num, keys, flag): skip filtering, reuse the resident pyramid
   std::vector<int> user_kindex;     // list position -> input index (_keypoint_index)
+  std::vector<int> user_levels;     // parity hook: explicit level index per user keypoint (hess_debug_key_levels)
   bool user_result = false;         // last results are in u_keys / u_desc (input order)
   std::vector<hess_keypoint> u_keys;
   std::vector<float> u_desc;
@@ -247,8 +248,9 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   const hess_params& p = c->p;
   int ds = 0, ws = width, hs = height;
   if (p.first_octave > 0) { ds = p.first_octave; ws = width >> ds; hs = height >> ds; }
+  else if (p.first_octave < 0) { ds = p.first_octave; ws = (width & ~3) << (-ds); hs = height << (-ds); }  // PyramidCU.cpp:120-138
   if (ws > p.tex_max_dim || hs > p.tex_max_dim) {
-    if (!p.auto_downscale) {
+    if (!p.auto_downscale || ds < 0) {
       set_err(c, "image %dx%d exceeds max dimension %d (use -ads or -maxd)", ws, hs, p.tex_max_dim);
       return HESS_ERR_TOO_BIG;
     }
@@ -322,6 +324,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->deth, (size_t)lvl * 4))) return rc;
   if ((rc = ensure(c, c->got, (size_t)gt * 8))) return rc;
   if ((rc = ensure(c, c->input_f32, (size_t)B * ws * hs * 4))) return rc;
+  if (ds < 0 && (rc = ensure(c, c->upsampled, (size_t)B * ws * hs * 4))) return rc;
   if ((rc = ensure(c, c->rowmask, (size_t)B * g.NM * 8))) return rc;
   if ((rc = ensure(c, c->rowcnt, (size_t)B * g.NR * 4))) return rc;
   if ((rc = ensure(c, c->rowoff, (size_t)B * g.NR * 4))) return rc;
@@ -409,6 +412,11 @@ void drain_profile(hess_ctx* c) {
   c->pending.clear();
 }
 
+// 2^_octave_min: scale of the first octave relative to the input (PyramidCU.cpp:566-569,746-748,1054-1057).
+static inline float first_octave_sigma(const hess_ctx* c) {
+  return c->ds > 0 ? (float)(1 << c->ds) : (c->ds < 0 ? 1.0f / (float)(1 << (-c->ds)) : 1.0f);
+}
+
 int enqueue_user(hess_ctx* c);
 
 // Enqueue the whole path for `batch` images whose pixels are at device address `dev`.
@@ -431,9 +439,14 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   const float* src_f = nullptr;
   if (!direct_u8) {
     ProfScope ps(c, HESS_K_INPUT, (double)batch * c->img_w * c->img_h * (4.0 + fmt_channels(format)));
-    launch_convert(st, dev, format, pixtype, pitch, (long long)image_stride, c->ds, (float*)c->input_f32.p,
-                   c->img_w, c->img_h, batch);
+    const int up = c->ds < 0 ? -c->ds : 0;  // up-sampled first octave: convert at full size, then SampleImageU
+    launch_convert(st, dev, format, pixtype, pitch, (long long)image_stride, up ? 0 : c->ds, (float*)c->input_f32.p,
+                   c->img_w >> up, c->img_h >> up, batch);
     src_f = (const float*)c->input_f32.p;
+    if (up) {  // PyramidCU.cpp:1521-1522
+      launch_upsample(st, src_f, c->img_w >> up, c->img_h >> up, up, (float*)c->upsampled.p, batch);
+      src_f = (const float*)c->upsampled.p;
+    }
   }
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
@@ -543,7 +556,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.normalize = p.normalize;
   dsp.multi = c->multi ? 1 : 0;
   dsp.lowe_origin = p.lowe_origin;
-  dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;  // PyramidCU.cpp:746-748
+  dsp.octave_sigma = first_octave_sigma(c);  // PyramidCU.cpp:746-748
   dsp.dog = g.dog;
   dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
@@ -574,7 +587,7 @@ int enqueue_user(hess_ctx* c) {
   const int num = (int)c->user_keys.size();
   const double twopi = 2.0 * 3.14159265358979323846;
   const float sigma_half_step = powf(2.0f, 0.5f / g.dog);
-  float octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+  float octave_sigma = first_octave_sigma(c);
   const float offset = p.lowe_origin ? 0.0f : 0.5f;
   std::vector<RawKey> hl;
   std::vector<FRec> hr;
@@ -587,7 +600,11 @@ int enqueue_user(hess_ctx* c) {
       const float sigma_max = level_sigma * sigma_half_step;
       for (int k = 0; k < num && hl.size() < cap; k++) {
         const hess_keypoint& key = c->user_keys[k];
-        const float sigmak = key.s;
+        float sigmak = key.s;
+        if ((int)c->user_levels.size() == num && c->user_levels[k] >= 0) {  // parity hook: level given, not derived
+          if (c->user_levels[k] != octave * g.dog + (level - 1)) continue;
+          sigmak = level_sigma;
+        }
         if (((sigmak >= sigma_min) && (sigmak < sigma_max)) || ((sigmak < sigma_min) && (octave == 0) && (level == 1)) ||
             ((sigmak > sigma_max) && (octave == g.noct - 1) && (level == g.dog))) {
           const float fX = (key.x - offset) / octave_sigma + 0.5f;
@@ -657,7 +674,7 @@ int enqueue_user(hess_ctx* c) {
   dsp.normalize = p.normalize;
   dsp.multi = 0;
   dsp.lowe_origin = p.lowe_origin;
-  dsp.octave_sigma = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+  dsp.octave_sigma = first_octave_sigma(c);
   dsp.dog = g.dog;
   dsp.dynamic_indexing = p.dynamic_indexing ? 1 : 0;
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
@@ -775,7 +792,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (!c) return nullptr;
   if (params) c->p = *params; else default_params(&c->p);
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
-      c->p.first_octave < 0) {
+      c->p.first_octave < -3) {  // "can't upsample by more than 8", PyramidCU.cpp:131-132
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;
@@ -801,7 +818,7 @@ void hess_destroy(hess_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
-  DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
+  DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->overflow, &c->raw, &c->sel, &c->hist, &c->sel_total,
                     &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
@@ -910,6 +927,13 @@ int hess_run_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys
   int rc = submit_impl(c, r);
   if (rc) { c->user_keys.clear(); return rc; }
   return wait_impl(c, r);
+}
+
+int hess_debug_key_levels(hess_ctx* c, const int* levels, int num) {
+  if (!c || num < 0) return HESS_ERR_ARG;
+  c->user_levels.clear();
+  if (levels && num > 0) c->user_levels.assign(levels, levels + num);
+  return 0;
 }
 
 int hess_count(hess_ctx* c, int img) {

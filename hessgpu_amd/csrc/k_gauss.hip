@@ -328,6 +328,41 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvArgs a) {
   a.dst[((long long)blockIdx.z * a.h + y) * a.w + x] = conv_pixel(p, a.format, a.pixtype);
 }
 
+// ---- UpsampleKernel<LOG_SCALE>, ProgramCU.cu:233-285: linear interpolation by 2^k; the source is addressed
+// by 1-D index (index+1 at a row end is the next row's first pixel, past the plane reads 0).  One thread per
+// (destination row, source column) writes 2^k adjacent outputs. ----
+__global__ __launch_bounds__(256) void upsample_kernel(const float* src, int width, int height, int log_scale,
+                                                       float* dst) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= width) return;
+  const int SCALE = 1 << log_scale;
+  const float INV_SCALE = 1.0f / (float)SCALE;
+  const int dst_row = blockIdx.y;
+  const int row = dst_row >> log_scale, helper = dst_row & (SCALE - 1);
+  const int n = width * height;
+  const float* plane = src + (long long)blockIdx.z * n;
+  const int index = row * width + col;
+  float v1, v2;
+  if (helper) {
+    const float v11 = gtex1(plane, n, index), v12 = gtex1(plane, n, index + 1);
+    const float v21 = gtex1(plane, n, index + width), v22 = gtex1(plane, n, index + width + 1);
+    const float w1 = INV_SCALE * helper, w2 = (float)(1.0 - w1);
+    v1 = fmaf(v21, w1, w2 * v11);  // :257
+    v2 = fmaf(v22, w1, w2 * v12);  // :258
+  } else {
+    v1 = gtex1(plane, n, index);
+    v2 = gtex1(plane, n, index + 1);
+  }
+  float* d = dst + ((long long)blockIdx.z * (height << log_scale) + dst_row) * ((long long)width << log_scale) +
+             ((long long)col << log_scale);
+  d[0] = v1;
+  for (int i = 1; i < SCALE; ++i) {
+    const float r2 = i * INV_SCALE;
+    const float r1 = 1.0f - r2;
+    d[i] = fmaf(v1, r1, v2 * r2);  // :267
+  }
+}
+
 // ---- DownsampleKernel<1>, ProgramCU.cu:312-326: dst(x,y) = src(min(2x, sw-1), 2y) ----
 __global__ __launch_bounds__(256) void downsample_kernel(const float* src, int sw, int splane, float* dst,
                                                          int dw, int dh) {
@@ -373,6 +408,11 @@ void launch_convert(hipStream_t st, const void* src, int format, int pixtype, lo
   a.src = (const uint8_t*)src; a.pitch = pitch; a.img_stride = img_stride;
   a.format = format; a.pixtype = pixtype; a.ds = ds; a.dst = dst; a.w = w; a.h = h;
   hipLaunchKernelGGL(convert_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, st, a);
+}
+
+void launch_upsample(hipStream_t st, const float* src, int w, int h, int log_scale, float* dst, int batch) {
+  hipLaunchKernelGGL(upsample_kernel, dim3((w + 255) / 256, h << log_scale, batch), dim3(256), 0, st, src, w, h,
+                     log_scale, dst);
 }
 
 void launch_downsample(hipStream_t st, const float* src, int sw, int splane, float* dst, int dw, int dh,

@@ -120,6 +120,14 @@ class Session:
         self._check(self._f["run_keypoints"](self._h, k.ctypes.data_as(C.c_void_p), len(k), int(have_orientation)))
         return self.count(0)
 
+    def debug_key_levels(self, levels=None):
+        """Parity hook: explicit level index per user keypoint for the following set/run_keypoints (None clears)."""
+        if levels is None:
+            self._check(self._f["debug_key_levels"](self._h, None, 0))
+            return
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        self._check(self._f["debug_key_levels"](self._h, lv.ctypes.data_as(C.c_void_p), len(lv)))
+
     def reserve(self, width, height, batch):
         self._check(self._f["reserve"](self._h, width, height, batch))
 

@@ -67,7 +67,11 @@ typedef struct hess_params {
   float orient_window_factor;   /* -w   (0=default 2.0)   GlobalUtil.cpp:134                  */
   float orient_gaussian_factor; /*      (0=default 1.5)   GlobalUtil.cpp:135                  */
   float desc_window_factor;     /* -dw  (0=default 3.0)   GlobalUtil.cpp:63                   */
-  int32_t first_octave;         /* -fo  (>=0; default 0)  SiftGPU.cpp:1166-1175               */
+  int32_t first_octave;         /* -fo  (default 0)  SiftGPU.cpp:1166-1175: the reference's Hessian build
+                                   takes only >= 0 at its option parser (and so does this build's
+                                   SiftGPU::ParseParam); -1..-3 = first octave up-sampled by 2^-fo
+                                   (PyramidCU.cpp:120-138,1517-1525, ProgramCU.cu:233-310), kept below the
+                                   parser in the reference and reachable here through this struct only */
   int32_t octave_num;           /* -no  (<=0 = no limit)  GlobalUtil.cpp:123                  */
   int32_t subpixel;             /* -s   (default 1)                                           */
   int32_t max_orientation;      /* -m   (default 2; clamped to 1..4 by ParseParam)            */
@@ -175,6 +179,10 @@ int hess_geometry(hess_ctx* ctx, int* widths, int* heights);
 
 /* Parity hooks (no reference counterpart; reference has only the GL viewer's level display). */
 int hess_debug_level(hess_ctx* ctx, int img, int octave, int level, int what, float* out);
+/* Parity hook for the reference's feature file (tests/test_reference_fixture.py): describe user keypoint k
+ * at level index levels[k] = octave*dog_level_num + (level-1) instead of the level the scale rule of
+ * GenerateFeatureListTex picks (-1 keeps the rule; NULL/0 clears).  Applies to later set/run_keypoints. */
+int hess_debug_key_levels(hess_ctx* ctx, const int* levels, int num);
 /* Raw detections of image `img` in list order; returns the count (<= cap written). */
 int hess_debug_list(hess_ctx* ctx, int img, hess_rawkey* out, int cap);
 

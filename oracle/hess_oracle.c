@@ -1,8 +1,9 @@
 /*
  * hess_oracle.c -- CPU ORACLE: plain-C restatement of the reference's Hessian + SIFT hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see hess_oracle.h).  PARITY UNPINNED: the reference has no golden
- * vectors for this path and cannot be built here; see hess_oracle.h and DESIGN.md.
+ * TEST INFRASTRUCTURE ONLY (see hess_oracle.h).  PARITY: detector UNPINNED (the reference has no golden
+ * vectors for the Hessian path and cannot be built here); orientation + descriptor stages pinned by the
+ * reference's doc/evaluation/box.siftgpu; see hess_oracle.h and DESIGN.md.
  *
  * Every function cites the reference lines it restates (paths relative to
  * /root/reference/src/SiftGPU/).  Floating-point model: IEEE binary32, round-to-nearest;
@@ -74,6 +75,7 @@ struct hess_cpu_ctx {
   /* user-supplied keypoint list for the next run (SiftPyramid::SetKeypointList) */
   hess_keypoint* user_keys;
   int user_num, user_have_orientation;
+  int* user_levels;            /* analysis hook: explicit level index per user keypoint (hess_cpu_debug_key_levels) */
   float timing[HESS_T_COUNT];
   char err[256];
 };
@@ -211,6 +213,53 @@ static inline float convert_pixel(const void* p, int format, int pixtype) {
   if (format == HESS_FMT_RGB || format == HESS_FMT_RGBA)
     return (float)(int32_t)(19595u * v0 + 38470u * v1 + 7471u * v2) / (65535.0f * factor);
   return (float)(int32_t)(7471u * v0 + 38470u * v1 + 19595u * v2) / (65535.0f * factor);
+}
+
+/* Scale of the first octave relative to the input image: 2^_octave_min (PyramidCU.cpp:746-748,
+ * 1054-1057, 566-569): 1 << ds for a decimated input, 1 / (1 << -ds) for an up-sampled one. */
+static float first_octave_sigma(const hess_cpu_ctx* c) {
+  if (c->ds > 0) return (float)(1 << c->ds);
+  if (c->ds < 0) return 1.0f / (float)(1 << (-c->ds));
+  return 1.0f;
+}
+
+/* UpsampleKernel<LOG_SCALE>, ProgramCU.cu:233-285 (SampleImageU :288-310): linear interpolation by
+ * 2^log_scale in both directions; the source is fetched by 1-D index (index+1 at a row end is the next
+ * row's first pixel, an index past the plane reads 0).  Only reachable with -fo < 0, which the
+ * reference's Hessian build refuses at the option parser (SiftGPU.cpp:1166-1167) although the pyramid
+ * code below it keeps the path (PyramidCU.cpp:1517-1525): the oracle has it so that the reference's own
+ * feature file (doc/evaluation/box.siftgpu, made with -fo -1) can be reproduced stage by stage. */
+static inline float tex1(const float* t, long n, long i);
+static void upsample_image(const float* src, int width, int height, int log_scale, float* dst) {
+  const int SCALE = 1 << log_scale, SCALE_MASK = SCALE - 1;
+  const float INV_SCALE = 1.0f / (float)SCALE;
+  const long n = (long)width * height;
+#pragma omp parallel for schedule(static)
+  for (int dst_row = 0; dst_row < (height << log_scale); dst_row++) {
+    int row = dst_row >> log_scale;
+    int helper = dst_row & SCALE_MASK;
+    for (int col = 0; col < width; col++) {
+      long index = (long)row * width + col;
+      long dst_idx = ((long)width * dst_row + col) * SCALE;
+      float v1, v2;
+      if (helper) {
+        float v11 = tex1(src, n, index), v12 = tex1(src, n, index + 1);
+        float v21 = tex1(src, n, index + width), v22 = tex1(src, n, index + width + 1);
+        float w1 = INV_SCALE * helper, w2 = (float)(1.0 - w1);
+        v1 = fmaf(v21, w1, w2 * v11);
+        v2 = fmaf(v22, w1, w2 * v12);
+      } else {
+        v1 = tex1(src, n, index);
+        v2 = tex1(src, n, index + 1);
+      }
+      dst[dst_idx] = v1;
+      for (int i = 1; i < SCALE; ++i) {
+        const float r2 = i * INV_SCALE;
+        const float r1 = 1.0f - r2;
+        dst[dst_idx + i] = fmaf(v1, r1, v2 * r2);
+      }
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -695,7 +744,8 @@ hess_cpu_ctx* hess_cpu_create(const hess_params* params) {
   hess_cpu_ctx* c = (hess_cpu_ctx*)calloc(1, sizeof(*c));
   if (!c) return NULL;
   if (params) c->p = *params; else hess_cpu_default_params(&c->p);
-  if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > 10) {
+  if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > 10 ||
+      c->p.first_octave < -3) { /* "can't upsample by more than 8", PyramidCU.cpp:131-132 */
     free(c);
     return NULL;
   }
@@ -709,8 +759,26 @@ void hess_cpu_destroy(hess_cpu_ctx* c) {
   if (!c) return;
   free_results(c);
   free(c->user_keys);
+  free(c->user_levels);
   free(c);
 }
+/* Analysis hook (tests/golden/analyze_box_fixture.py): describe user keypoint k at level index
+ * levels[k] = octave * dog + (level - 1) instead of the level GenerateFeatureListTex's scale rule picks
+ * (-1 keeps the rule).  A detected keypoint is described at its DETECTION level, whose sigma is within one
+ * scale step of the keypoint's scale, not within half a step: the hook lets a test ask which of the two
+ * admissible levels the reference used.  Applies to the following hess_cpu_set/run_keypoints calls. */
+int hess_cpu_debug_key_levels(hess_cpu_ctx* c, const int* levels, int num) {
+  if (!c || num < 0) return HESS_ERR_ARG;
+  free(c->user_levels);
+  c->user_levels = NULL;
+  if (levels && num > 0) {
+    c->user_levels = (int*)malloc((size_t)num * sizeof(int));
+    if (!c->user_levels) return HESS_ERR_NOMEM;
+    memcpy(c->user_levels, levels, (size_t)num * sizeof(int));
+  }
+  return 0;
+}
+
 void hess_cpu_set_threads(hess_cpu_ctx* c, int t) { c->threads = t < 1 ? 1 : t; }
 void hess_cpu_keep_levels(hess_cpu_ctx* c, int on) { c->keep = on; }
 
@@ -723,6 +791,10 @@ static int plan_geometry(hess_cpu_ctx* c, int width, int height) {
     ds = p->first_octave;
     ws = width >> ds;
     hs = height >> ds;
+  } else if (p->first_octave < 0) { /* InitPyramid, PyramidCU.cpp:120-138: truncate, then up-sample */
+    ds = p->first_octave;
+    ws = (width & ~3) << (-ds);
+    hs = height << (-ds);
   }
   if (ws > p->tex_max_dim || hs > p->tex_max_dim) {
     if (!p->auto_downscale) {
@@ -730,6 +802,7 @@ static int plan_geometry(hess_cpu_ctx* c, int width, int height) {
                p->tex_max_dim);
       return HESS_ERR_TOO_BIG;
     }
+    if (ds < 0) { snprintf(c->err, sizeof(c->err), "up-sampled image exceeds max dimension"); return HESS_ERR_TOO_BIG; }
     do { ds++; ws >>= 1; hs >>= 1; } while (ws > p->tex_max_dim || hs > p->tex_max_dim);
   }
   ws &= ~3; /* TruncateWidthCU, GLTexImage.h:127 */
@@ -789,8 +862,7 @@ static int user_keypoint_path(hess_cpu_ctx* c, image_result* R) {
   pyramid* py = &R->pyr;
   const double twopi = 2.0 * PI_D;
   float sigma_half_step = powf(2.0f, 0.5f / dog);
-  float octave_sigma = 1.0f;
-  if (c->ds > 0) octave_sigma *= (float)(1 << c->ds);
+  float octave_sigma = first_octave_sigma(c);
   float offset = p->lowe_origin ? 0.0f : 0.5f;
   int cap = 2 * num + 8;
   frec* recs = (frec*)malloc((size_t)cap * sizeof(frec));
@@ -805,6 +877,10 @@ static int user_keypoint_path(hess_cpu_ctx* c, image_result* R) {
       float sigma_max = level_sigma * sigma_half_step;
       for (int k = 0; k < num && n < cap; k++) {
         float sigmak = uk[k].s;
+        if (c->user_levels && c->user_levels[k] >= 0) { /* analysis hook: level given, not derived */
+          sigmak = (c->user_levels[k] == octave * dog + (level - 1)) ? level_sigma : -1.0f;
+          if (sigmak < 0) continue;
+        }
         if (((sigmak >= sigma_min) && (sigmak < sigma_max)) || ((sigmak < sigma_min) && (octave == 0) && (level == 1)) ||
             ((sigmak > sigma_max) && (octave == c->noct - 1) && (level == dog))) {
           float fX = (uk[k].x - offset) / octave_sigma + 0.5f;
@@ -837,7 +913,7 @@ static int user_keypoint_path(hess_cpu_ctx* c, image_result* R) {
   int download = !c->user_have_orientation && ((p->max_orientation < 2) || p->fixed_orientation);
   int listed = n < num ? n : num;
   if (download) {
-    float os = (c->ds > 0) ? (float)(1 << c->ds) : 1.0f;
+    float os = first_octave_sigma(c);
     for (int i = 0; i < listed; i++) {
       int li = rlevel[i];
       float oss = os * (float)(1 << (li / dog));
@@ -888,7 +964,8 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   double t0 = now_ms(), t1;
 
   /* --- input: decimate by 2^ds, convert, drop W mod 4 columns (GLTexImage.cpp:993-1011) --- */
-  int W = c->img_w, H = c->img_h, step = 1 << c->ds;
+  const int up = c->ds < 0 ? -c->ds : 0; /* up-sampled first octave: convert at full size, SampleImageU below */
+  int W = c->img_w >> up, H = c->img_h >> up, step = 1 << (c->ds > 0 ? c->ds : 0);
   float* input = (float*)malloc((size_t)W * H * sizeof(float));
   if (!input) return HESS_ERR_NOMEM;
 #pragma omp parallel for schedule(static)
@@ -896,6 +973,13 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     for (int x = 0; x < W; x++)
       input[(size_t)r * W + x] =
           convert_pixel(pix + (size_t)(r * step) * pitch + (size_t)(x * step) * nch * bpc, format, pixtype);
+  if (up) { /* PyramidCU.cpp:1521-1522 */
+    float* big = (float*)malloc((size_t)c->img_w * c->img_h * sizeof(float));
+    if (!big) { free(input); return HESS_ERR_NOMEM; }
+    upsample_image(input, W, H, up, big);
+    free(input);
+    input = big;
+  }
   (void)width; (void)height;
   t1 = now_ms(); c->timing[HESS_T_LOAD] += (float)(t1 - t0); t0 = t1;
 
@@ -1081,8 +1165,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   {
     const double twopi = 2.0 * PI_D;
     const double factor = 2.0 * PI_D / 255.0;
-    float octave_sigma = 1.0f; /* _octave_min = 0 */
-    if (c->ds > 0) octave_sigma *= (float)(1 << c->ds);
+    float octave_sigma = first_octave_sigma(c); /* 2^_octave_min */
     float offset = p->lowe_origin ? 0.0f : 0.5f;
     int m = 0;
     for (int n = 0; n < feature_num; n++) {
