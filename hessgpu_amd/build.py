@@ -42,6 +42,27 @@ def _run(cmd):
     return r
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """Developer A/B builds: tools/_variants/<name>/libhessgpu.so compiled with extra flags (e.g. -DHESS_DESC_WAVES=6);
+    select it at run time with HESS_LIB=<path>.  Not part of the product build."""
+    vdir = os.path.join(HERE, "..", "tools", "_variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    objs, jobs = [], []
+    for src in KERNEL_SOURCES:
+        o = os.path.join(vdir, src + ".o")
+        objs.append(o)
+        jobs.append([HIPCC] + CXXFLAGS + FILE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(_run, jobs))
+    lib = os.path.join(vdir, "libhessgpu.so")
+    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print("built variant:", lib)
+    return lib
+
+
 def build_all(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
@@ -84,4 +105,7 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python -m hessgpu_amd.build --variant NAME [flags...]
+        build_variant(sys.argv[2], sys.argv[3:], verbose=True)
+    else:
+        build_all(force="--force" in sys.argv, verbose=True)

@@ -16,6 +16,8 @@
 //                box per iteration, hits are appended in order to the cell's LDS list, and lane (cell, q)
 //                owns bins q, q+4 (q = 0 also 8) of its cell and walks the list (see descriptor_kernel).
 // Built without the SLP vectoriser (hessgpu_amd/build.py): packed FP32 issues at half rate on gfx950.
+#include <type_traits>
+
 #include "hess_dev.h"
 #include "hess_devmath.h"
 
@@ -294,31 +296,89 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 
 // ================================= descriptor ================================================
 
-// Records a cell's list holds between two drains.  32 (17 KB of lists per workgroup, six wavefronts per
-// SIMD by registers) measured 6 % faster than 64 (four wavefronts per SIMD by LDS); 16-24 drain too often.
-constexpr int DL_CAP = 32;
-constexpr int DL_STRIDE = DL_CAP + 2;  // list pitch in records: 68 dwords = 4 (mod 64) -> the 16 lists of a
-                               // wavefront start in different LDS banks (conflict-free b128 reads)
+// LDS coefficient table of the descriptor kernel: [cell 0..15][bin 0..11][sample slot s 0..3] floats per wavefront.
+// Column s of a cell is all zeros except, while the samples of the current iteration are being accumulated, w1 at
+// bin floor(theta_s) and w2 at the next bin.  The four slots of a bin are adjacent, so a lane fetches the four
+// coefficients of one of its bins with one 16-byte read, and a cell's 48 floats keep the 16 lanes of a read group
+// on 16 different 4-bank groups (conflict-free).
+constexpr int DC_BINS = 12;
+constexpr int DC_ROWS = 16 * DC_BINS * 4;
 
-// One wavefront per feature.  Lane = cell*4 + q.
-//   phase 1  the four lanes of a cell take four consecutive samples of the cell's box per iteration
-//            (scan order of ProgramCU.cu:1723-1774: y outer, x inner), so the 16 cells advance together
-//            with no cross-lane broadcast; hits are appended, in scan order, to the cell's list in LDS;
-//   phase 2  ("drain") lane (cell, q) owns the accumulators des[q], des[q+4] (q = 0 also des[8]) of
-//            its cell and walks the list in order: one fmaf per record and bin, exactly the reference's
-//            `des[fidx] += w1*weight; des[fidx+1] += w2*weight` sequence for every bin.
-// The coefficient of bin j for a record is written as med3(0, (j+1)-theta, theta-(j-1)): for
-// floor(theta) == j that is w1 = fo+1-theta, for floor(theta) == j-1 it is w2 = theta-fo (same single
-// subtraction as the reference), otherwise 0 -- and fmaf(0, weight, acc) == acc because weights and
-// accumulators are non-negative and finite.
-__global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
-                                                         int cap_list, const FRec* recs,
-                                                         const int* fsrc, const int* feat_total,
-                                                         const int* feat_first, const int* img_base,
-                                                         const float* got, HostKeypoint* keys, float* desc,
-                                                         int cap_feat) {
+// e^x for the descriptor's Gaussian window: same operations and results as dm_expf() on -87 <= x <= 88 (there
+// its two range clamps select nothing, and p * 2^n by v_ldexp is the same single rounding as the multiplication
+// by the constructed power of two); arguments here lie in [-1.5625, 0] for every sample that is used.
+__device__ __forceinline__ float dm_expf_inrange(float x) {
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float z = r * r;
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, r, 1.3981999507E-3f);
+  p = fmaf(p, r, 8.3334519073E-3f);
+  p = fmaf(p, r, 4.1665795894E-2f);
+  p = fmaf(p, r, 1.6666665459E-1f);
+  p = fmaf(p, r, 5.0000001201E-1f);
+  p = fmaf(p, z, r);
+  p = p + 1.0f;
+  return __builtin_amdgcn_ldexpf(p, (int)n);
+}
+
+// N consecutive iterations of a lane of the descriptor kernel: window coordinates, window test, gathered (gradient, theta)
+template <int N_>
+struct DescChunk {
+  static constexpr int N = N_;
+  float nx[N_], ny[N_];
+  float2 cc[N_];
+  bool in[N_];
+};
+
+// acc += coef * (w of lane 4*(lane/4)+S of the caller's quad): one v_fmac_f32 with the quad broadcast as its DPP
+// operand (the compiler keeps the broadcast as a separate v_mov_b32_dpp otherwise); a single fused multiply-add
+// either way, so the value is the one fmaf() gives.
+#ifndef HESS_DESC_ASMDPP
+#define HESS_DESC_ASMDPP 1
+#endif
+template <int S>
+__device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
+#if HESS_DESC_ASMDPP
+  static_assert(S >= 0 && S < 4, "quad lane");
+  if (S == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
+  if (S == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
+  if (S == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
+  if (S == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
+#else
+  const float wb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w), S * 0x55, 0xF, 0xF, true));
+  acc = fmaf(coef, wb, acc);
+#endif
+}
+
+// One wavefront per feature.  Lane = cell*4 + sub.
+//   scan   the four lanes of a cell take four consecutive samples of the cell's box per iteration (scan order of
+//          ProgramCU.cu:1723-1774: y outer, x inner), so the 16 cells advance together; a lane steps its own
+//          sample four places along the scan by exact float increments (no index division), evaluates the
+//          reference's window test, weights and bin coordinate for it (a sample outside the window or past the box
+//          gets weight 0);
+//   add    lane (cell, q) owns the accumulators des[q], des[q+4], des[q+8] of its cell (des[8] is the reference's
+//          ninth bin, des[9..11] stay unused).  The samples of an iteration are added in scan order s = 0..3: the
+//          lane that evaluated sample s has put its two bin coefficients (w1 at floor(theta), w2 at the next bin)
+//          into an otherwise zero LDS row; every lane of the cell reads the three coefficients of its own bins and
+//          does `des += coefficient * weight` -- the reference's `des[fidx] += w1*weight; des[fidx+1] += w2*weight`
+//          for the two bins that are touched and `+= 0 * weight` (no change: weights and sums are finite and
+//          non-negative) for the others.  Per bin the additions therefore happen in the reference's order.
+// No sample lists, no compaction: per iteration a lane does two 2-dword LDS stores (set, clear) and three 16-byte loads.
+#ifdef HESS_DESC_WAVES
+#define HESS_DESC_BOUNDS __launch_bounds__(256, HESS_DESC_WAVES)
+#else
+#define HESS_DESC_BOUNDS __launch_bounds__(256)
+#endif
+__global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
+                                                   int cap_list, const FRec* recs,
+                                                   const int* fsrc, const int* feat_total,
+                                                   const int* feat_first, const int* img_base,
+                                                   const float* got, HostKeypoint* keys, float* desc,
+                                                   int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
-  __shared__ __attribute__((aligned(16))) float2 rec_lds[4][16 * DL_STRIDE];
+  __shared__ __attribute__((aligned(16))) float crow[4][DC_ROWS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int ftotal = feat_total[b], ffirst = feat_first[b];
@@ -327,15 +387,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;
   const int mycell = lane >> 2, sub = lane & 3;
-  float2* const rlist = &rec_lds[wv][0];
-  float2* const mylist = rlist + mycell * DL_STRIDE;
-  // stale list entries are read (with weight forced to 0) when lists have different lengths: make
-  // sure they are finite from the start
-  for (int i = lane; i < 16 * DL_STRIDE; i += 64) rlist[i] = make_float2(0.0f, 0.0f);
-  // bin constants of this lane: des[sub] and des[sub+4]; des[8] only gets w2 of floor(theta) == 7
-  const float jlo1 = (float)(sub + 1), jlom = (float)(sub - 1);
-  const float jhi1 = (float)(sub + 5), jhim = (float)(sub + 3);
-  const float j8m = (sub == 0) ? 7.0f : 1.0e6f;
+  float* const rows = &crow[wv][0];
+  for (int i = lane; i < DC_ROWS; i += 64) rows[i] = 0.0f;
+  float* const mycol = rows + mycell * (DC_BINS * 4) + sub;              // + 4*bin: the column this lane fills (slot `sub`)
+  const float4* const rdbin = reinterpret_cast<const float4*>(rows + mycell * (DC_BINS * 4) + sub * 4);  // [0], [4], [8]: bins sub, sub+4, sub+8
   const float theta_end = dp.dynamic_indexing ? 8.00000095f : 8.0f;  // next float after 8: admits theta == 8 only
 
   for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
@@ -347,7 +402,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     int o, l;
     level_of(g, li, &o, &l);
     const OctGeom& og = g.o[o];
-    const float2* gp = reinterpret_cast<const float2*>(got) + og.got_off + ((long long)(l - 1) * g.B + b) * og.plane;
+    // the feature, and with it the gradient plane, is the same in all lanes: keep the plane's address in scalar
+    // registers so that a gather is `scalar base + 32-bit lane offset`
+    const unsigned long long gpa = (unsigned long long)(reinterpret_cast<const float2*>(got) + og.got_off +
+                                                        ((long long)(l - 1) * g.B + b) * og.plane);
+    const char* const gp = reinterpret_cast<const char*>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gpa >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(gpa & 0xFFFFFFFFull)));
     const int width = og.wa, height = og.h;
 
     // un-mirrored orientation handed to the kernel (PyramidCU.cpp:764,791; A.1 of SURVEY)
@@ -392,84 +453,126 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     const int nxs = (xmax >= xmin) ? (int)(xmax - xmin) + 1 : 0;
     const int nys = (ymax >= ymin) ? (int)(ymax - ymin) + 1 : 0;
     const int total = nxs * nys;
-    const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
-    // sample (sx, sy) of the box is pixel (xmin+sx, ymin+sy): (int)y * width + (int)x = base + sy*width + sx
-    const int base = (int)ymin * width + (int)xmin;
     int maxtotal = total;
 #pragma unroll
     for (int d = 32; d >= 4; d >>= 1) maxtotal = max(maxtotal, __shfl_xor(maxtotal, d));
     maxtotal = rli(maxtotal, 0);
     const int nit = (maxtotal + 3) >> 2;
+    // A lane's sample t = 4*iteration + sub sits at pixel centre (xf, yf) = (xmin + t % nxs, ymin + t / nxs), byte
+    // offset `goff` in the gradient plane.  Rows of four or more samples (every box of a real keypoint) are
+    // walked by increments: four places along x, and back by a row's length onto the next row when that passes
+    // xmax -- all values are integers + 0.5 far below 2^23, so the float steps are exact.  Boxes narrower than
+    // four samples (degenerate scales) take the division form; the choice is uniform over the wavefront.
+    const bool narrow = __any((nxs > 0) & (nxs < 4));
+    const float fnxs = (float)nxs;
+    const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
+    const int base = (int)ymin * width + (int)xmin;  // (int)y * width + (int)x of sample (0, 0)
+    float xf = xmin + (float)sub;
+    float yf = (total > 0) ? ymin : 3.0e38f;  // an empty box never yields a valid sample
+    unsigned goff = (unsigned)(base + sub) * 8u;
+    const float xwrap = xmax - 4.0f;           // stepping from beyond this lands past the row's end
+    const int rowskip = (width - nxs + 4) * 8;  // byte step onto the next row instead of +32
 
-    float acc_lo = 0.0f, acc_hi = 0.0f, acc_8 = 0.0f;
-    int cnt = 0;  // records in this cell's list (same value in the four lanes of the cell)
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // des[sub], des[sub+4], des[sub+8]
 
-    auto update = [&](float theta, float w) {
-      const float c0 = __builtin_amdgcn_fmed3f(0.0f, jlo1 - theta, theta - jlom);  // ProgramCU.cu:1752-1753
-      acc_lo = fmaf(c0, w, acc_lo);
-      const float c1 = __builtin_amdgcn_fmed3f(0.0f, jhi1 - theta, theta - jhim);
-      acc_hi = fmaf(c1, w, acc_hi);
-      const float c8 = fmaxf(0.0f, theta - j8m);
-      acc_8 = fmaf(c8, w, acc_8);
-    };
-    auto drain = [&]() {
-      for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
-        const float4 ra = *reinterpret_cast<const float4*>(mylist + s0);
-        const float4 rb = *reinterpret_cast<const float4*>(mylist + s0 + 2);
-        update(ra.x, (s0 < cnt) ? ra.y : 0.0f);
-        update(ra.z, (s0 + 1 < cnt) ? ra.w : 0.0f);
-        update(rb.x, (s0 + 2 < cnt) ? rb.y : 0.0f);
-        update(rb.z, (s0 + 3 < cnt) ? rb.w : 0.0f);
-      }
-      cnt = 0;
-    };
-
-    for (int it0 = 0; it0 < nit; it0 += 4) {
-      if (__any(cnt > DL_CAP - 16)) drain();
-      // stage A (4 iterations): geometry, window test, and the gradient gathers issued back to back
-      bool in[4];
-      float nxa[4], nya[4];
-      float2 cca[4];
+#ifndef HESS_DESC_UNROLL
+#define HESS_DESC_UNROLL 4
+#endif
+#ifndef HESS_DESC_PREFETCH
+#define HESS_DESC_PREFETCH 1
+#endif
+    // stage A: window test and the gradient gathers of N iterations, issued back to back.  Iterations past the end
+    // of the scan are harmless: their samples fail the window test (yf > ymax) and gather from offset 0.
+    auto stage_a = [&](auto narrow_tag, int it0, auto& ck) {
+      constexpr bool NARROW = decltype(narrow_tag)::value;
+      constexpr int N = std::remove_reference_t<decltype(ck)>::N;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int t = (it0 + u) * 4 + sub;
-        const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
-        const int sx = t - __mul24(sy, nxs);  // box sides are far below 2^23: 24-bit multiplies are exact
-        const float x = xmin + (float)sx, y = ymin + (float)sy;
-        const float dx = x - ptx, dy = y - pty;
-        nxa[u] = fmaf(crspt, dx, srspt * dy);
-        nya[u] = fmaf(crspt, dy, -(srspt * dx));
-        in[u] = (t < total) & (fabsf(nxa[u]) < 1.0f) & (fabsf(nya[u]) < 1.0f);
-        cca[u] = gp[in[u] ? base + __mul24(sy, width) + sx : 0];
+      for (int u = 0; u < N; u++) {
+        if (NARROW) {
+          const int t = (it0 + u) * 4 + sub;
+          const int sy = (int)(((float)t + 0.5f) * inv);  // = t / nxs (exact: |error| << 0.5/nxs)
+          const int sx = t - __mul24(sy, nxs);
+          xf = xmin + (float)sx;
+          yf = (t < total) ? ymin + (float)sy : 3.0e38f;
+          goff = (unsigned)(base + __mul24(sy, width) + sx) * 8u;
+        }
+        const float dx = xf - ptx, dy = yf - pty;
+        ck.nx[u] = fmaf(crspt, dx, srspt * dy);
+        ck.ny[u] = fmaf(crspt, dy, -(srspt * dx));
+        ck.in[u] = (yf <= ymax) & (fabsf(ck.nx[u]) < 1.0f) & (fabsf(ck.ny[u]) < 1.0f);
+        ck.cc[u] = *reinterpret_cast<const float2*>(gp + (ck.in[u] ? goff : 0u));
+        if (!NARROW) {
+          const bool wrap = xf > xwrap;
+          xf += wrap ? 4.0f - fnxs : 4.0f;
+          yf += wrap ? 1.0f : 0.0f;
+          goff += wrap ? (unsigned)rowskip : 32u;
+        }
       }
-      // stage B: weights, ordered append to the cell's list
+    };
+    // stage B: weight and bin coordinate of the lane's own sample, then the ordered accumulation of the
+    // iteration's four samples into every lane's bins
+    auto stage_b = [&](const auto& ck) {
+      constexpr int N = std::remove_reference_t<decltype(ck)>::N;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float nxn = fabsf(nxa[u]), nyn = fabsf(nya[u]);
-        const float dnx = nxa[u] + offx, dny = nya[u] + offy;
-        const float ww = dm_expf(-0.125f * fmaf(dnx, dnx, dny * dny));
+      for (int u = 0; u < N; u++) {
+        const float nxn = fabsf(ck.nx[u]), nyn = fabsf(ck.ny[u]);
+        const float dnx = ck.nx[u] + offx, dny = ck.ny[u] + offy;
+        const float ww = dm_expf_inrange(-0.125f * fmaf(dnx, dnx, dny * dny));
         const float wx = 1.0f - nxn, wy = 1.0f - nyn;
-        const float wt = ww * wx * wy * cca[u].x;
-        float theta = (anglef - cca[u].y) * rpi;
+        float wt = ww * wx * wy * ck.cc[u].x;
+        float theta = (anglef - ck.cc[u].y) * rpi;
         theta = (theta < 0) ? theta + 8.0f : theta;
         // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771);
-        // with -di it adds w1*weight = weight to des[8] (:1755-1759; the write to des[9] adds 0) -- which is
-        // what the bin-8 coefficient max(0, theta - 7) gives once the record is let through
-        const bool hit = in[u] & (theta >= 0.0f) & (theta < theta_end);
-        const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
-        const uint32_t nib = (uint32_t)(mk >> (lane & 60)) & 15u;  // hits of this cell's four lanes
-        // misses go to the padding slot of the list (never read), so the chunk stays branch-free
-        mylist[hit ? cnt + __popc(nib & ((1u << sub) - 1u)) : DL_STRIDE - 1] = make_float2(theta, wt);
-        cnt += __popc(nib);
+        // with -di it adds w1*weight = weight to des[8] (:1755-1759; the write to des[9] adds 0)
+        const bool hit = ck.in[u] & (theta >= 0.0f) & (theta < theta_end);
+        wt = hit ? wt : 0.0f;
+        const float fo = floorf(theta);
+        const float w1 = fo + 1.0f - theta, w2 = theta - fo;  // ProgramCU.cu:1752-1753
+        const int fidx = min(max((int)fo, 0), DC_BINS - 2);  // 0..8 for every finite theta; never outside the table
+        mycol[fidx * 4] = w1;
+        mycol[fidx * 4 + 4] = w2;
+        const float4 c0 = rdbin[0], c1 = rdbin[4], c2 = rdbin[8];
+        quad_fma<0>(acc0, c0.x, wt); quad_fma<0>(acc1, c1.x, wt); quad_fma<0>(acc2, c2.x, wt);
+        quad_fma<1>(acc0, c0.y, wt); quad_fma<1>(acc1, c1.y, wt); quad_fma<1>(acc2, c2.y, wt);
+        quad_fma<2>(acc0, c0.z, wt); quad_fma<2>(acc1, c1.z, wt); quad_fma<2>(acc2, c2.z, wt);
+        quad_fma<3>(acc0, c0.w, wt); quad_fma<3>(acc1, c1.w, wt); quad_fma<3>(acc2, c2.w, wt);
+        mycol[fidx * 4] = 0.0f;
+        mycol[fidx * 4 + 4] = 0.0f;
       }
-    }
-    drain();
-    if (sub == 0) acc_lo += acc_8;  // des[0] += des[8], ProgramCU.cu:1776
-    if (dp.half_sift) {
-      dl[wv][mycell * 4 + sub] = acc_lo + acc_hi;  // des[k] += des[k+4], ProgramCU.cu:1782-1785
+    };
+    if (narrow) {  // degenerate scales only: one iteration at a time
+      for (int it0 = 0; it0 < nit; it0++) {
+        DescChunk<1> ck;
+        stage_a(std::true_type{}, it0, ck);
+        stage_b(ck);
+      }
     } else {
-      dl[wv][mycell * 8 + sub] = acc_lo;
-      dl[wv][mycell * 8 + 4 + sub] = acc_hi;
+      constexpr int UN = HESS_DESC_UNROLL;
+#if HESS_DESC_PREFETCH
+      // software pipeline: the gathers of the next chunk are in flight while the current chunk is accumulated
+      DescChunk<UN> ca, cb;
+      stage_a(std::false_type{}, 0, ca);
+      for (int it0 = 0; it0 < nit; it0 += 2 * UN) {
+        stage_a(std::false_type{}, it0 + UN, cb);
+        stage_b(ca);
+        if (it0 + UN >= nit) break;
+        stage_a(std::false_type{}, it0 + 2 * UN, ca);
+        stage_b(cb);
+      }
+#else
+      for (int it0 = 0; it0 < nit; it0 += UN) {
+        DescChunk<UN> ck;
+        stage_a(std::false_type{}, it0, ck);
+        stage_b(ck);
+      }
+#endif
+    }
+    if (sub == 0) acc0 += acc2;  // des[0] += des[8], ProgramCU.cu:1776
+    if (dp.half_sift) {
+      dl[wv][mycell * 4 + sub] = acc0 + acc1;  // des[k] += des[k+4], ProgramCU.cu:1782-1785
+    } else {
+      dl[wv][mycell * 8 + sub] = acc0;
+      dl[wv][mycell * 8 + 4 + sub] = acc1;
     }
     // same wavefront wrote dl[wv]; LDS operations of one wavefront complete in order
     float* dout = desc + (obase + oidx) * dim;
