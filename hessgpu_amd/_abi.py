@@ -115,6 +115,8 @@ PRODUCT_PROTOTYPES = {
                              C.c_int, C.c_int]),
     "submit_device": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                 C.c_int, C.c_int]),
+    "submit_host": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                              C.c_int, C.c_int]),
     "wait": (C.c_int, [_ctx]),
     "device_results": (C.c_int, [_ctx, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_int)]),
     "profile_enable": (C.c_int, [_ctx, C.c_int]),

@@ -91,12 +91,12 @@ def build_all(force=False, verbose=False):
         apps_dir = os.path.join(HERE, "..", "apps")
         bindir = os.path.join(HERE, "bin")
         os.makedirs(bindir, exist_ok=True)
-        for app in ("hess", "speed"):
+        for app in ("hess", "speed", "multithread"):
             src = os.path.join(apps_dir, app + ".cpp")
             exe = os.path.join(bindir, app)
             if os.path.exists(src) and (force or _newer([src, api_hdr, api], exe)):
                 _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(HERE, "..", "include"), src, "-o", exe,
-                      "-L", HERE, "-lsiftgpu", "-lhessgpu", "-Wl,-rpath,$ORIGIN/.."])
+                      "-L", HERE, "-lsiftgpu", "-lhessgpu", "-pthread", "-Wl,-rpath,$ORIGIN/.."])
             if os.path.exists(exe):
                 built.append(exe)
     if verbose:

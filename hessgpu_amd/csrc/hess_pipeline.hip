@@ -55,6 +55,7 @@ struct PendingRun {
   size_t image_stride;
   double t_load_ms;
   bool active;
+  bool timed_load;  // ev_load[] bracket a host->device transfer of this batch
 };
 
 struct hess_ctx {
@@ -81,6 +82,8 @@ struct hess_ctx {
   std::vector<int> counts;
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
+  DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
+  hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
   // results written by the descriptor kernel straight into the pinned host buffers (no D2H pass after it)
   bool host_direct = false, host_direct_allowed = true;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
@@ -379,8 +382,8 @@ int plan(hess_ctx* c, int width, int height, int batch) {
 // ---- profiling helpers ----
 hipEvent_t get_event(hess_ctx* c) {
   if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
-  hipEvent_t e;
-  (void)hipEventCreate(&e);
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) { set_err(c, "hipEventCreate failed: profiling disabled"); c->prof = false; return nullptr; }
   return e;
 }
 struct ProfScope {
@@ -390,6 +393,12 @@ struct ProfScope {
   ProfScope(hess_ctx* ctx, int kernel, double bytes) : c(ctx), on(ctx->prof) {
     if (!on) return;
     ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes;
+    if (!ep.a || !ep.b) {  // event creation failed: no record for this launch
+      if (ep.a) c->pool.push_back(ep.a);
+      if (ep.b) c->pool.push_back(ep.b);
+      on = false;
+      return;
+    }
     (void)hipEventRecord(ep.a, c->st);
   }
   ~ProfScope() {
@@ -494,7 +503,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   LimitParams lp;
   lp.method = p.truncate_method;
   lp.threshold = p.feature_count_threshold;
-  (void)hipMemsetAsync(c->overflow.p, 0, 16, st);
+  HIP_TRY(c, hipMemsetAsync(c->overflow.p, 0, 16, st));
   {
     // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
     double det_bytes = 0;
@@ -633,7 +642,7 @@ int enqueue_user(hess_ctx* c) {
   }
   int* hs = (int*)c->h_small.p;
   hs[3 * g.B + 4] = n;
-  (void)hipMemsetAsync(c->overflow.p, 0, 16, st);
+  HIP_TRY(c, hipMemsetAsync(c->overflow.p, 0, 16, st));
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->raw.p, hl.data(), (size_t)n * sizeof(RawKey), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->recs.p, hr.data(), (size_t)n * sizeof(FRec), hipMemcpyHostToDevice, st));
@@ -763,6 +772,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
   memset(c->timing, 0, sizeof(c->timing));
   auto el = [&](int i, int j) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; };
   c->timing[HESS_T_LOAD] = (float)r.t_load_ms;
+  if (r.timed_load) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_load[0], c->ev_load[1]); c->timing[HESS_T_LOAD] = ms; }
   c->timing[HESS_T_PYRAMID] = el(0, 1);
   c->timing[HESS_T_DETECT] = el(1, 2);
   c->timing[HESS_T_LIST] = el(2, 3);
@@ -781,6 +791,11 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
 extern "C" {
 
 void hess_default_params(hess_params* p) { if (p) default_params(p); }
+
+int hess_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 hess_ctx* hess_create(int device, const hess_params* params) {
   int ndev = 0;
@@ -808,9 +823,16 @@ hess_ctx* hess_create(int device, const hess_params* params) {
     delete c;
     return nullptr;
   }
-  for (int i = 0; i < 8; i++) (void)hipEventCreate(&c->ev[i]);
-  { const char* zc = getenv("HESS_HOST_DIRECT"); c->host_direct_allowed = !(zc && zc[0] == '0'); }
+  bool ev_ok = true;
+  for (int i = 0; i < 8; i++) { c->ev[i] = nullptr; ev_ok = ev_ok && hipEventCreate(&c->ev[i]) == hipSuccess; }
+  for (int i = 0; i < 2; i++) { c->ev_load[i] = nullptr; ev_ok = ev_ok && hipEventCreate(&c->ev_load[i]) == hipSuccess; }
   c->have_ev = true;
+  if (!ev_ok) {
+    fprintf(stderr, "hessgpu: cannot create events on device %d\n", device);
+    hess_destroy(c);
+    return nullptr;
+  }
+  { const char* zc = getenv("HESS_HOST_DIRECT"); c->host_direct_allowed = !(zc && zc[0] == '0'); }
   return c;
 }
 
@@ -826,7 +848,11 @@ void hess_destroy(hess_ctx* c) {
   release(c->h_keys, true);
   release(c->h_desc, true);
   release(c->h_small, true);
-  if (c->have_ev) for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
+  release(c->h_stage, true);
+  if (c->have_ev) {
+    for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; i++) if (c->ev_load[i]) (void)hipEventDestroy(c->ev_load[i]);
+  }
   for (auto& ep : c->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->st) (void)hipStreamDestroy(c->st);
@@ -858,7 +884,7 @@ int hess_submit_device(hess_ctx* c, const void* dev_pixels, int width, int heigh
   if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->pend) c->pend = new PendingRun();
-  *c->pend = PendingRun{dev_pixels, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false};
+  *c->pend = PendingRun{dev_pixels, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, false};
   rc = submit_impl(c, *c->pend);
   if (rc) return rc;
   c->pend->active = true;
@@ -880,8 +906,13 @@ int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, 
   return hess_wait(c);
 }
 
-int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
-                  int format, int pixtype) {
+// Host pixels: one asynchronous host->device transfer on the context's stream, then the path.  Pinned caller
+// memory (hipHostMalloc / hipHostRegister) is read by the copy engine directly; pageable memory is first copied
+// into the context's pinned staging buffer by the calling thread -- while the device still works on the batches
+// of other contexts -- so that the transfer itself never blocks the host or the other streams of the device
+// (a hipMemcpyAsync from pageable memory does both).
+int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
+                     int format, int pixtype) {
   int rc = check_run_args(c, pixels, width, height, pitch, batch, format, pixtype);
   if (rc) return rc;
   if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
@@ -889,18 +920,31 @@ int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pi
   const size_t bytes = (size_t)(batch - 1) * image_stride + (size_t)height * pitch;
   rc = ensure(c, c->stage, bytes + 16);
   if (rc) return rc;
-  hipEvent_t a = c->ev[0], b = c->ev[1];
-  (void)hipEventRecord(a, c->st);
-  HIP_TRY(c, hipMemcpyAsync(c->stage.p, pixels, bytes, hipMemcpyHostToDevice, c->st));
-  (void)hipEventRecord(b, c->st);
-  HIP_TRY(c, hipStreamSynchronize(c->st));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, a, b);
+  const void* src = pixels;
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, pixels) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) {
+    (void)hipGetLastError();  // an unregistered pointer is reported as an error: not one
+    if ((rc = ensure(c, c->h_stage, bytes, true))) return rc;
+    memcpy(c->h_stage.p, pixels, bytes);
+    src = c->h_stage.p;
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_load[0], c->st));
+  HIP_TRY(c, hipMemcpyAsync(c->stage.p, src, bytes, hipMemcpyHostToDevice, c->st));
+  HIP_TRY(c, hipEventRecord(c->ev_load[1], c->st));
   if (!c->pend) c->pend = new PendingRun();
-  *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, (double)ms, false};
+  *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, true};
   rc = submit_impl(c, *c->pend);
   if (rc) return rc;
-  return wait_impl(c, *c->pend);
+  c->pend->active = true;
+  return 0;
+}
+
+int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
+                  int format, int pixtype) {
+  int rc = hess_submit_host(c, pixels, width, height, pitch, image_stride, batch, format, pixtype);
+  if (rc) return rc;
+  return hess_wait(c);
 }
 
 int hess_set_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {

@@ -915,7 +915,8 @@ void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& d
 
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
                  unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch) {
-  hipMemsetAsync(hist, 0, (size_t)batch * kHistBins * sizeof(unsigned), st);
+  // a failure here is picked up with the launches' by the hipGetLastError() that follows the enqueue (submit_impl)
+  (void)hipMemsetAsync(hist, 0, (size_t)batch * kHistBins * sizeof(unsigned), st);
   hipLaunchKernelGGL(topk_hist_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, K, raw, raw_total,
                      cap_raw, hist);
   hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist, sel,

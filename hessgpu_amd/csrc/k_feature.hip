@@ -296,13 +296,18 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 
 // ================================= descriptor ================================================
 
-// LDS coefficient table of the descriptor kernel: [cell 0..15][bin 0..11][sample slot s 0..3] floats per wavefront.
-// Column s of a cell is all zeros except, while the samples of the current iteration are being accumulated, w1 at
-// bin floor(theta_s) and w2 at the next bin.  The four slots of a bin are adjacent, so a lane fetches the four
-// coefficients of one of its bins with one 16-byte read, and a cell's 48 floats keep the 16 lanes of a read group
-// on 16 different 4-bank groups (conflict-free).
+// LDS coefficient table of the descriptor kernel: [bin 0..11][cell 0..15 (+pad)][sample slot s 0..3] floats per
+// wavefront.  Column (cell, s) is all zeros except, while the samples of the current iteration are being
+// accumulated, w1 at bin floor(theta_s) and w2 at the next bin.  The four slots of a (bin, cell) are adjacent, so a
+// lane fetches the four coefficients of one of its bins with one 16-byte read.  Bin pitch 80 floats (64 + 16):
+//   stores  a lane's bank is 16*(bin & 1) + 4*(cell mod 8) + s -- whatever bins the 32 lanes of a store group
+//           hit, at most two of them share a bank (free for 4-byte stores); with the bins of a cell adjacent (the
+//           first layout tried) lanes of equal bin collided 4-way and conflicts took half of all LDS cycles;
+//   loads   the 16 lanes of a 16-byte read group (cells {0,3,5,6}, {1,2,4,7}, ... x q) fall on 16 different 4-bank
+//           groups: 4*q + cell is distinct modulo 16 within every group.
 constexpr int DC_BINS = 12;
-constexpr int DC_ROWS = 16 * DC_BINS * 4;
+constexpr int DC_BIN_PITCH = 80;
+constexpr int DC_ROWS = DC_BINS * DC_BIN_PITCH;
 
 // e^x for the descriptor's Gaussian window: same operations and results as dm_expf() on -87 <= x <= 88 (there
 // its two range clamps select nothing, and p * 2^n by v_ldexp is the same single rounding as the multiplication
@@ -389,8 +394,8 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
   const int mycell = lane >> 2, sub = lane & 3;
   float* const rows = &crow[wv][0];
   for (int i = lane; i < DC_ROWS; i += 64) rows[i] = 0.0f;
-  float* const mycol = rows + mycell * (DC_BINS * 4) + sub;              // + 4*bin: the column this lane fills (slot `sub`)
-  const float4* const rdbin = reinterpret_cast<const float4*>(rows + mycell * (DC_BINS * 4) + sub * 4);  // [0], [4], [8]: bins sub, sub+4, sub+8
+  float* const mycol = rows + mycell * 4 + sub;  // + DC_BIN_PITCH*bin: the column this lane fills (cell, slot `sub`)
+  const float* const rdbin = rows + sub * DC_BIN_PITCH + mycell * 4;  // + 4*DC_BIN_PITCH*k: bins sub, sub+4, sub+8
   const float theta_end = dp.dynamic_indexing ? 8.00000095f : 8.0f;  // next float after 8: admits theta == 8 only
 
   for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
@@ -529,15 +534,17 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
         const float fo = floorf(theta);
         const float w1 = fo + 1.0f - theta, w2 = theta - fo;  // ProgramCU.cu:1752-1753
         const int fidx = min(max((int)fo, 0), DC_BINS - 2);  // 0..8 for every finite theta; never outside the table
-        mycol[fidx * 4] = w1;
-        mycol[fidx * 4 + 4] = w2;
-        const float4 c0 = rdbin[0], c1 = rdbin[4], c2 = rdbin[8];
+        mycol[fidx * DC_BIN_PITCH] = w1;
+        mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = w2;
+        const float4 c0 = *reinterpret_cast<const float4*>(rdbin);
+        const float4 c1 = *reinterpret_cast<const float4*>(rdbin + 4 * DC_BIN_PITCH);
+        const float4 c2 = *reinterpret_cast<const float4*>(rdbin + 8 * DC_BIN_PITCH);
         quad_fma<0>(acc0, c0.x, wt); quad_fma<0>(acc1, c1.x, wt); quad_fma<0>(acc2, c2.x, wt);
         quad_fma<1>(acc0, c0.y, wt); quad_fma<1>(acc1, c1.y, wt); quad_fma<1>(acc2, c2.y, wt);
         quad_fma<2>(acc0, c0.z, wt); quad_fma<2>(acc1, c1.z, wt); quad_fma<2>(acc2, c2.z, wt);
         quad_fma<3>(acc0, c0.w, wt); quad_fma<3>(acc1, c1.w, wt); quad_fma<3>(acc2, c2.w, wt);
-        mycol[fidx * 4] = 0.0f;
-        mycol[fidx * 4 + 4] = 0.0f;
+        mycol[fidx * DC_BIN_PITCH] = 0.0f;
+        mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = 0.0f;
       }
     };
     if (narrow) {  // degenerate scales only: one iteration at a time

@@ -6,9 +6,9 @@ ServerSiftGPU.cpp:156-194).  Here: one process per GPU, image i of a batch goes 
 owns the contiguous block containing i, each rank runs the whole path locally, and the only
 exchange step is the gather of the variable-length feature lists to one rank -- an all_gather of
 the per-image counts (a few integers that are already on the host: over a gloo side group when
-enable_host_count_exchange() was called, else through the data group) followed by one padded gather
-of keypoints and one of descriptors (torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs,
-"gloo" in the CPU tests).
+enable_host_count_exchange() was called, else through the data group) followed by one grouped batch of
+exact-size sends of keypoints and descriptors to the destination rank (torch.distributed: backend "nccl" =
+RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
 """
 import numpy as np
 import torch
@@ -62,40 +62,48 @@ def _exchange_counts(counts, dev, world, group):
 
 
 def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
-    """Gather per-image feature lists to rank `dst`.
+    """Gather per-image feature lists to rank `dst`, every rank sending exactly its own records.
 
     counts    list[int], features per local image (same number of local images on every rank)
     keys_u8   uint8 tensor [sum(counts), 24]  (hess_keypoint records, local images back to back)
     desc_f32  float32 tensor [sum(counts), dim] or None when descriptors are off
     Returns on dst: (all_counts [world][n_local], keys list[world] of uint8 [n_r,24],
     desc list[world] of float32 [n_r,dim] or None); on other ranks (all_counts, None, None).
+
+    The counts are exchanged first (every rank then knows every block size), after which rank r sends its
+    n_r x 24 and n_r x dim blocks to dst with one grouped batch of point-to-point operations (RCCL: one
+    ncclGroup of send/recv pairs over xGMI; no padding to the largest rank, nothing sent for an empty rank;
+    dst's own block is not copied at all).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = keys_u8.device
     all_counts = _exchange_counts(counts, dev, world, group)
     totals = [int(sum(c)) for c in all_counts]
-    pad = max(max(totals), 1)
-
-    def padded(t, width, dtype):
-        # rows beyond the rank's own total are never looked at on dst: no need to clear them
-        out = torch.empty((pad, width), dtype=dtype, device=dev)
-        if t is not None and t.shape[0]:
-            out[: t.shape[0]] = t
-        return out
-
-    kp = padded(keys_u8, KEY_BYTES, torch.uint8)
-    klist = [torch.empty_like(kp) for _ in range(world)] if rank == dst else None
-    dist.gather(kp, gather_list=klist, dst=dst, group=group)
-    dlist = None
-    if desc_f32 is not None:
-        dp = padded(desc_f32, desc_f32.shape[1], torch.float32)
-        dlist = [torch.empty_like(dp) for _ in range(world)] if rank == dst else None
-        dist.gather(dp, gather_list=dlist, dst=dst, group=group)
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    dim = desc_f32.shape[1] if desc_f32 is not None else 0
+    ops = []
+    if rank == dst:
+        keys = [keys_u8 if r == dst else torch.empty((totals[r], KEY_BYTES), dtype=torch.uint8, device=dev)
+                for r in range(world)]
+        desc = None
+        if desc_f32 is not None:
+            desc = [desc_f32 if r == dst else torch.empty((totals[r], dim), dtype=torch.float32, device=dev)
+                    for r in range(world)]
+        for r in range(world):
+            if r != dst and totals[r] > 0:
+                ops.append(dist.P2POp(dist.irecv, keys[r], peer(r), group))
+                if desc is not None:
+                    ops.append(dist.P2POp(dist.irecv, desc[r], peer(r), group))
+    elif totals[rank] > 0:
+        ops.append(dist.P2POp(dist.isend, keys_u8.contiguous(), peer(dst), group))
+        if desc_f32 is not None:
+            ops.append(dist.P2POp(dist.isend, desc_f32.contiguous(), peer(dst), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return all_counts, None, None
-    keys = [klist[r][: totals[r]] for r in range(world)]
-    desc = [dlist[r][: totals[r]] for r in range(world)] if dlist is not None else None
     return all_counts, keys, desc
 
 

@@ -105,6 +105,19 @@ class Session:
                                              pitch * height, batch, fmt, pixtype))
         self._batch = batch
 
+    def submit_host(self, images=None, fmt=None, ptr=None, batch=None, height=None, width=None):
+        """Asynchronous half of run(): host pixels (a numpy array, or a raw host pointer `ptr` to `batch` u8
+        luminance images, e.g. a pinned torch tensor's .data_ptr()) -> enqueue transfer + path, return."""
+        if ptr is not None:
+            pitch = width
+            self._check(self._f["submit_host"](self._h, C.c_void_p(ptr), width, height, pitch, pitch * height, batch,
+                                               _abi.FMT_LUM, _abi.PIX_U8))
+            self._batch = batch
+            return
+        a, b, h, w, pitch, stride, fmt, pix = self._describe(images, fmt)
+        self._check(self._f["submit_host"](self._h, a.ctypes.data_as(C.c_void_p), w, h, pitch, stride, b, fmt, pix))
+        self._batch = b
+
     def wait(self):
         """Block until the submitted batch's keypoints and descriptors are in host memory."""
         self._check(self._f["wait"](self._h))

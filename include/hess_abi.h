@@ -123,6 +123,10 @@ typedef struct hess_ctx hess_ctx; /* opaque */
 /* Fill *p with the reference defaults (all "0=default" fields resolved). */
 void hess_default_params(hess_params* p);
 
+/* Number of usable HIP devices (0 without a GPU): what the reference's callers hard-code as "device 0 and 1"
+ * (TestWin/MultiThreadSIFT.cpp:233-234; ProgramCU::CheckCudaDevice, ProgramCU.cu:3386-3440, rejects the rest). */
+int hess_device_count(void);
+
 /* Replaces SiftGPU::CreateContextGL/VerifyContextGL -> InitSiftGPU -> new PyramidCU
  * (SiftGPU.cpp:149-227,1516-1539) and ProgramCU::CheckCudaDevice (ProgramCU.cu:3386-3440).
  * `device` is the HIP device ordinal.  Returns NULL on failure. */
@@ -145,6 +149,11 @@ int hess_run_host(hess_ctx* ctx, const void* pixels, int width, int height, int 
  * result transfer of one batch with the kernels of the next.  One submitted batch per context. */
 int hess_submit_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
                        size_t image_stride, int batch, int format, int pixtype);
+/* The same from host memory: the pixels cross with one asynchronous transfer on the context's stream (straight
+ * from the caller's buffer when it is pinned, through the context's pinned staging buffer otherwise; the buffer
+ * may be reused as soon as the call returns in the second case, after hess_wait in the first). */
+int hess_submit_host(hess_ctx* ctx, const void* pixels, int width, int height, int pitch,
+                     size_t image_stride, int batch, int format, int pixtype);
 int hess_wait(hess_ctx* ctx);
 /* Same, pixels already resident in device memory (HBM) of ctx's device. */
 int hess_run_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,

@@ -18,7 +18,8 @@ def test_bench_json_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_secondary", "cpu_baseline",
+              "value_host_to_host", "latency_ms_single_image", "parity_checked", "kernel_ms_per_step"):
         assert k in d, k
     assert d["unit"] == "Mpix/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -27,5 +28,10 @@ def test_bench_json_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    kernels = {rf["kernel"].split()[0], d["roofline_secondary"]["kernel"].split()[0]}
+    assert kernels == {"gauss_kernel", "descriptor_kernel"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
+    assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
+    assert 0 < d["value_host_to_host"] and 0 < d["latency_ms_single_image"] < 100
+    assert d["config"]["distinct_images_per_gpu"] == 2 and "configs[1]" in d["config"]["workload"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mpix/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]

@@ -53,3 +53,29 @@ def test_speed_harness_reports_stable_counts(tmp_path):
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "+++++" in r.stdout and "e" not in r.stdout.splitlines()[0] and "Hz" in r.stdout
+
+
+def test_multithread_driver_one_instance_per_thread_per_device(tmp_path):
+    """apps/multithread.cpp, the reference's multi-GPU pattern (TestWin/MultiThreadSIFT.cpp:83-156,231-244): one
+    SiftGPU instance per host thread per device, initialised under a mutex, RunSIFT() repeated without a lock.
+    Runs on every visible device (one here, all of them on a multi-GPU node), two instances per device."""
+    names = ["640-1.jpg", "640-3.jpg"]
+    lums = [fixtures.load_rgb(n)[..., 1].copy() for n in names]
+    args = [os.path.join(BIN, "multithread"), "-n", "20", "-per-device", "2"]
+    for n, l in zip(names, lums):
+        _write_pgm(tmp_path / (n[:-4] + ".pgm"), l)
+        args += ["-i", str(tmp_path / (n[:-4] + ".pgm"))]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("#")]
+    import torch
+
+    assert len(lines) == 2 * torch.cuda.device_count() and r.stdout.splitlines()[-1].startswith("OK")
+    o = OracleSession(threads=8, keep_levels=False)
+    want = {}
+    for n, l in zip(names, lums):
+        o.run(l[None])
+        want[n[:-4] + ".pgm"] = o.count(0)
+    for l in lines:                      # "#t: device d, path: N features, H Hz"
+        path, rest = l.split(", ", 1)[1].split(": ")
+        assert int(rest.split()[0]) == want[os.path.basename(path)] and float(rest.split(", ")[1].split()[0]) > 0

@@ -83,13 +83,16 @@ def test_two_rank_gather_matches_single_process(tmp_path):
 
 
 def test_gather_handles_ranks_with_no_features(tmp_path):
-    """Empty and ragged lists: one rank contributes nothing (SURVEY 8c edge cases)."""
+    """Empty and ragged lists: the destination itself contributes nothing, the others blocks of different
+    sizes; every rank sends exactly its own records (SURVEY 8c edge cases)."""
     out = str(tmp_path / "g2.npz")
-    mp.spawn(_ragged_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_ragged_worker, args=(3, _free_port(), out), nprocs=3, join=True)
     got = np.load(out)
-    assert got["counts"].tolist() == [0, 3]
-    assert got["keys"].shape == (3, 24) and got["desc"].shape == (3, 128)
-    assert np.array_equal(got["desc"][:, 0], np.array([1.0, 2.0, 3.0], np.float32))
+    assert got["counts"].tolist() == [0, 3, 5]
+    assert got["sizes"].tolist() == [0, 3, 5]                      # received blocks are not padded to the largest
+    assert got["keys"].shape == (8, 24) and got["desc"].shape == (8, 128)
+    assert got["keys"][:, 0].tolist() == [1, 1, 1, 2, 2, 2, 2, 2]
+    assert np.array_equal(got["desc"][:, 0], np.array([1.0, 2.0, 3.0, 1.0, 2.0, 3.0, 4.0, 5.0], np.float32))
 
 
 def _ragged_worker(rank, world, port, result_path):
@@ -98,12 +101,12 @@ def _ragged_worker(rank, world, port, result_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n = 0 if rank == 0 else 3
+        n = [0, 3, 5][rank]
         keys = torch.full((n, 24), rank, dtype=torch.uint8)
         desc = torch.arange(1, n + 1, dtype=torch.float32)[:, None].repeat(1, 128)
         all_counts, gk, gd = hdist.gather_feature_lists([n], keys, desc, dst=0)
         if rank == 0:
-            np.savez(result_path, counts=np.array([c for r in all_counts for c in r]),
+            np.savez(result_path, counts=np.array([c for r in all_counts for c in r]), sizes=np.array([len(k) for k in gk]),
                      keys=np.concatenate([k.numpy() for k in gk]), desc=np.concatenate([d.numpy() for d in gd]))
     finally:
         dist.destroy_process_group()
