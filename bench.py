@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[3]: 64 images over 8 GPUs)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images per GPU (0 = --batch: all distinct)")
-    ap.add_argument("--contexts", type=int, default=6, help="contexts (streams) pipelined per GPU")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) pipelined per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")

@@ -308,6 +308,8 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 constexpr int DC_BINS = 12;
 constexpr int DC_BIN_PITCH = 80;
 constexpr int DC_ROWS = DC_BINS * DC_BIN_PITCH;
+// dynamic LDS requested at launch on top of the static 17 KB: 36 KB per workgroup -> at most 4 workgroups per CU
+constexpr int DC_LDS_PAD_BYTES = 36 * 1024 - 4 * (4 * DC_ROWS + 4 * 128);
 
 // e^x for the descriptor's Gaussian window: same operations and results as dm_expf() on -87 <= x <= 88 (there
 // its two range clamps select nothing, and p * 2^n by v_ldexp is the same single rounding as the multiplication
@@ -337,24 +339,15 @@ struct DescChunk {
   bool in[N_];
 };
 
-// acc += coef * (w of lane 4*(lane/4)+S of the caller's quad): one v_fmac_f32 with the quad broadcast as its DPP
-// operand (the compiler keeps the broadcast as a separate v_mov_b32_dpp otherwise); a single fused multiply-add
-// either way, so the value is the one fmaf() gives.
-#ifndef HESS_DESC_ASMDPP
-#define HESS_DESC_ASMDPP 1
-#endif
+// acc += coef * (w of lane 4*(lane/4)+S of the caller's quad): quad broadcast by DPP, then one fused multiply-add.
+// (The broadcast stays a compiler-visible v_mov_b32_dpp on purpose: folded into the multiply-add by inline
+// assembly it saved nothing measurable, and the compiler cannot see the wait states a DPP read of a freshly
+// written register needs inside an asm statement.)
 template <int S>
 __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
-#if HESS_DESC_ASMDPP
   static_assert(S >= 0 && S < 4, "quad lane");
-  if (S == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
-  if (S == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
-  if (S == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
-  if (S == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(coef));
-#else
   const float wb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w), S * 0x55, 0xF, 0xF, true));
   acc = fmaf(coef, wb, acc);
-#endif
 }
 
 // One wavefront per feature.  Lane = cell*4 + sub.
@@ -371,17 +364,16 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
 //          for the two bins that are touched and `+= 0 * weight` (no change: weights and sums are finite and
 //          non-negative) for the others.  Per bin the additions therefore happen in the reference's order.
 // No sample lists, no compaction: per iteration a lane does two 2-dword LDS stores (set, clear) and three 16-byte loads.
-#ifdef HESS_DESC_WAVES
-#define HESS_DESC_BOUNDS __launch_bounds__(256, HESS_DESC_WAVES)
-#else
-#define HESS_DESC_BOUNDS __launch_bounds__(256)
-#endif
-__global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
-                                                   int cap_list, const FRec* recs,
-                                                   const int* fsrc, const int* feat_total,
-                                                   const int* feat_first, const int* img_base,
-                                                   const float* got, HostKeypoint* keys, float* desc,
-                                                   int cap_feat) {
+// Occupancy: four workgroups (= four wavefronts per SIMD) per CU, enforced by the LDS footprint (DC_LDS_PAD_BYTES).
+// The kernel is bound by vector issue, not by latency: builds with 2, 3 and 4 wavefronts per SIMD run alike, builds
+// with 5, 6 or 8 (fewer registers, or smaller unroll) measured 5-30 % slower (profiles/README.md, round 2), so the
+// register count must not decide it.
+__global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
+                                                         int cap_list, const FRec* recs,
+                                                         const int* fsrc, const int* feat_total,
+                                                         const int* feat_first, const int* img_base,
+                                                         const float* got, HostKeypoint* keys, float* desc,
+                                                         int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
   __shared__ __attribute__((aligned(16))) float crow[4][DC_ROWS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -396,7 +388,7 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
   for (int i = lane; i < DC_ROWS; i += 64) rows[i] = 0.0f;
   float* const mycol = rows + mycell * 4 + sub;  // + DC_BIN_PITCH*bin: the column this lane fills (cell, slot `sub`)
   const float* const rdbin = rows + sub * DC_BIN_PITCH + mycell * 4;  // + 4*DC_BIN_PITCH*k: bins sub, sub+4, sub+8
-  const float theta_end = dp.dynamic_indexing ? 8.00000095f : 8.0f;  // next float after 8: admits theta == 8 only
+  const uint32_t theta_end_bits = dp.dynamic_indexing ? 0x41000001u : 0x41000000u;  // 8.0f, or the next float (admits theta == 8)
 
   for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
     const int src = fsrc[(long long)b * cap_feat + m];
@@ -480,12 +472,6 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
 
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // des[sub], des[sub+4], des[sub+8]
 
-#ifndef HESS_DESC_UNROLL
-#define HESS_DESC_UNROLL 4
-#endif
-#ifndef HESS_DESC_PREFETCH
-#define HESS_DESC_PREFETCH 1
-#endif
     // stage A: window test and the gradient gathers of N iterations, issued back to back.  Iterations past the end
     // of the scan are harmless: their samples fail the window test (yf > ymax) and gather from offset 0.
     auto stage_a = [&](auto narrow_tag, int it0, auto& ck) {
@@ -516,6 +502,13 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
     };
     // stage B: weight and bin coordinate of the lane's own sample, then the ordered accumulation of the
     // iteration's four samples into every lane's bins
+    // the four samples of one iteration, in scan order, into this lane's three bins
+    auto accumulate = [&](const float4& c0, const float4& c1, const float4& c2, float wt) {
+      quad_fma<0>(acc0, c0.x, wt); quad_fma<0>(acc1, c1.x, wt); quad_fma<0>(acc2, c2.x, wt);
+      quad_fma<1>(acc0, c0.y, wt); quad_fma<1>(acc1, c1.y, wt); quad_fma<1>(acc2, c2.y, wt);
+      quad_fma<2>(acc0, c0.z, wt); quad_fma<2>(acc1, c1.z, wt); quad_fma<2>(acc2, c2.z, wt);
+      quad_fma<3>(acc0, c0.w, wt); quad_fma<3>(acc1, c1.w, wt); quad_fma<3>(acc2, c2.w, wt);
+    };
     auto stage_b = [&](const auto& ck) {
       constexpr int N = std::remove_reference_t<decltype(ck)>::N;
 #pragma unroll
@@ -529,7 +522,9 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
         theta = (theta < 0) ? theta + 8.0f : theta;
         // DYNAMIC_INDEXING=false: a sample with floor(theta) == 8 adds nothing (ProgramCU.cu:1763-1771);
         // with -di it adds w1*weight = weight to des[8] (:1755-1759; the write to des[9] adds 0)
-        const bool hit = ck.in[u] & (theta >= 0.0f) & (theta < theta_end);
+        // 0 <= theta < theta_end as ONE unsigned compare of the bit patterns (negative values and NaNs have larger
+        // patterns than any non-negative bound); theta is never -0: the angles subtracted above are not
+        const bool hit = ck.in[u] & (__float_as_uint(theta) < theta_end_bits);
         wt = hit ? wt : 0.0f;
         const float fo = floorf(theta);
         const float w1 = fo + 1.0f - theta, w2 = theta - fo;  // ProgramCU.cu:1752-1753
@@ -539,10 +534,7 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
         const float4 c0 = *reinterpret_cast<const float4*>(rdbin);
         const float4 c1 = *reinterpret_cast<const float4*>(rdbin + 4 * DC_BIN_PITCH);
         const float4 c2 = *reinterpret_cast<const float4*>(rdbin + 8 * DC_BIN_PITCH);
-        quad_fma<0>(acc0, c0.x, wt); quad_fma<0>(acc1, c1.x, wt); quad_fma<0>(acc2, c2.x, wt);
-        quad_fma<1>(acc0, c0.y, wt); quad_fma<1>(acc1, c1.y, wt); quad_fma<1>(acc2, c2.y, wt);
-        quad_fma<2>(acc0, c0.z, wt); quad_fma<2>(acc1, c1.z, wt); quad_fma<2>(acc2, c2.z, wt);
-        quad_fma<3>(acc0, c0.w, wt); quad_fma<3>(acc1, c1.w, wt); quad_fma<3>(acc2, c2.w, wt);
+        accumulate(c0, c1, c2, wt);
         mycol[fidx * DC_BIN_PITCH] = 0.0f;
         mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = 0.0f;
       }
@@ -554,8 +546,7 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
         stage_b(ck);
       }
     } else {
-      constexpr int UN = HESS_DESC_UNROLL;
-#if HESS_DESC_PREFETCH
+      constexpr int UN = 4;
       // software pipeline: the gathers of the next chunk are in flight while the current chunk is accumulated
       DescChunk<UN> ca, cb;
       stage_a(std::false_type{}, 0, ca);
@@ -566,13 +557,6 @@ __global__ HESS_DESC_BOUNDS void descriptor_kernel(Geom g, DescParams dp, const 
         stage_a(std::false_type{}, it0 + 2 * UN, ca);
         stage_b(cb);
       }
-#else
-      for (int it0 = 0; it0 < nit; it0 += UN) {
-        DescChunk<UN> ck;
-        stage_a(std::false_type{}, it0, ck);
-        stage_b(ck);
-      }
-#endif
     }
     if (sub == 0) acc0 += acc2;  // des[0] += des[8], ProgramCU.cu:1776
     if (dp.half_sift) {
@@ -659,7 +643,7 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   int blocks = (cap_feat + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), 0, st, g, dp, list, cap_list, recs, fsrc,
+  hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
                      feat_total, feat_first, img_base, got, keys, desc, cap_feat);
 }
 

@@ -24,6 +24,7 @@ namespace {
 
 constexpr int TW = 64, TH = 32, NT = 256;
 
+
 struct GaussArgs {
   const float* src;
   const uint8_t* src_u8;
@@ -117,80 +118,80 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
 
   // ---- stage 1b (HESS): det-Hessian*sigma^4 and (gradient, theta) of the SOURCE level for this tile,
   // straight from the staged source window: the level is never re-read from HBM for it
-  // (ComputeHessian_Kernel, ProgramCU.cu:523-595).  A thread does 8 pixels of one row. ----
+  // (ComputeHessian_Kernel, ProgramCU.cu:523-595).  A thread does 4 adjacent pixels in each of two rows 16 apart:
+  // its det-H store is 16 bytes next to its neighbours' (256 contiguous bytes per row and instruction) and its
+  // gradient/theta stores are two 16-byte pieces at a 32-byte lane pitch.  (8 pixels of one row per thread meant
+  // four 16-byte pieces at a 64-byte pitch, a shape that stores at half the rate: tools/micro/store_rate.hip.) ----
   if (HESS) {
-    const int hr = tid >> 3, hx = (tid & 7) * 8;
-    const int gy = y0 + hr, gx = x0 + hx;
-    if (gy < h && gx < w) {
-      float U[10], M[10], D[10];  // columns gx-1 .. gx+8 of rows gy-1, gy, gy+1
-      {
-        const float* base = &s[(hr + R - 1) * SWP + hx + R4 - 4];
-        float tmp[3][16];
+    const int hx = (tid & 15) * 4;
+    const int gx = x0 + hx;
+    const bool want_got = a.got_src != nullptr;  // block-uniform
+    const float* plane = a.src + img * a.src_img_stride;
+    const int n = w * h;
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+    for (int half = 0; half < 2; half++) {
+      const int hr = (tid >> 4) + 16 * half;
+      const int gy = y0 + hr;
+      if (gy < h && gx < w) {
+        float U[6], M[6], D[6];  // columns gx-1 .. gx+4 of rows gy-1, gy, gy+1
+        {
+          const float* base = &s[(hr + R - 1) * SWP + hx + R4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const float4 v = *reinterpret_cast<const float4*>(base + rr * SWP + 4 * q);
-            tmp[rr][4 * q] = v.x; tmp[rr][4 * q + 1] = v.y; tmp[rr][4 * q + 2] = v.z; tmp[rr][4 * q + 3] = v.w;
+          for (int rr = 0; rr < 3; rr++) {
+            float* dst = rr == 0 ? U : (rr == 1 ? M : D);
+            const float4 v = *reinterpret_cast<const float4*>(base + rr * SWP);
+            dst[0] = base[rr * SWP - 1];
+            dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
+            dst[5] = base[rr * SWP + 4];
           }
-#pragma unroll
-        for (int j = 0; j < 10; j++) { U[j] = tmp[0][3 + j]; M[j] = tmp[1][3 + j]; D[j] = tmp[2][3 + j]; }
-      }
-      // The staged window replicates the image border; the reference addresses neighbours by 1-D
-      // index instead: rows outside the plane read 0, column -1 / w wraps to the adjacent row.
-      const float* plane = a.src + img * a.src_img_stride;
-      const int n = w * h, idx = gy * w + gx;
-      if (gy == 0) {
-#pragma unroll
-        for (int j = 0; j < 10; j++) U[j] = 0.0f;
-      }
-      if (gy == h - 1) {
-#pragma unroll
-        for (int j = 0; j < 10; j++) D[j] = 0.0f;
-      }
-      if (gx == 0) {
-        U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
-      }
-      const int nvalid = (w - gx) >= 8 ? 8 : 4;  // w is a multiple of 4
-      if (gx + nvalid == w) {                    // this thread owns the row's last pixel
-        const int il = idx + nvalid - 1;
-        const float ur = gtex1(plane, n, il - w + 1), mr = gtex1(plane, n, il + 1), dr = gtex1(plane, n, il + w + 1);
-        if (nvalid == 8) { U[9] = ur; M[9] = mr; D[9] = dr; } else { U[5] = ur; M[5] = mr; D[5] = dr; }
-      }
-      float hv[8];
-      float2 gv[8];
-      const bool want_got = a.got_src != nullptr;  // block-uniform
-      // two pixels at a time on 2-vectors, no per-pixel branches
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-#define HESS_V2(A, K) ((v2f){A[(K)], A[(K) + 1]})
-        const v2f v11 = HESS_V2(U, j), v12 = HESS_V2(U, j + 1), v13 = HESS_V2(U, j + 2);
-        const v2f v21 = HESS_V2(M, j), v22 = HESS_V2(M, j + 1), v23 = HESS_V2(M, j + 2);
-        const v2f v31 = HESS_V2(D, j), v32 = HESS_V2(D, j + 1), v33 = HESS_V2(D, j + 2);
-#undef HESS_V2
-        const v2f Lxx = v2_fma(v2_splat(-2.0f), v22, v21) + v23;   // ProgramCU.cu:536
-        const v2f Lyy = v2_fma(v2_splat(-2.0f), v22, v12) + v32;   // :537
-        const v2f Lxy = (v13 - v11 + v31 - v33) * v2_splat(0.25f);  // :538
-        const v2f dh = v2_fma(Lxx, Lyy, -(Lxy * Lxy)) * v2_splat(a.norm_src);  // :553
-        hv[j] = dh.x; hv[j + 1] = dh.y;
-        if (want_got) {
-          const v2f dx = v23 - v21, dy = v32 - v12;                 // :556-557
-          const v2f gradient = v2_splat(0.5f) * __builtin_elementwise_sqrt(v2_fma(dx, dx, dy * dy));
-          const v2f th = dm_atan2f_x2(dy, dx);
-          gv[j].x = gradient.x;     gv[j].y = (gradient.x == 0.0f) ? 0.0f : th.x;
-          gv[j + 1].x = gradient.y; gv[j + 1].y = (gradient.y == 0.0f) ? 0.0f : th.y;
         }
-      }
-      const long long o = img * (long long)w * h + idx;
-      *reinterpret_cast<float4*>(a.deth_src + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-      if (nvalid == 8) *reinterpret_cast<float4*>(a.deth_src + o + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
-      if (want_got) {
-        float2* gp = a.got_src + o;
-        *reinterpret_cast<float4*>(gp) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
-        *reinterpret_cast<float4*>(gp + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
-        if (nvalid == 8) {
-          *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4].x, gv[4].y, gv[5].x, gv[5].y);
-          *reinterpret_cast<float4*>(gp + 6) = make_float4(gv[6].x, gv[6].y, gv[7].x, gv[7].y);
+        // The staged window replicates the image border; the reference addresses neighbours by 1-D
+        // index instead: rows outside the plane read 0, column -1 / w wraps to the adjacent row.
+        const int idx = gy * w + gx;
+        if (gy == 0) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) U[j] = 0.0f;
+        }
+        if (gy == h - 1) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) D[j] = 0.0f;
+        }
+        if (gx == 0) {
+          U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
+        }
+        if (gx + 4 == w) {  // this thread owns the row's last pixel (w is a multiple of 4)
+          const int il = idx + 3;
+          U[5] = gtex1(plane, n, il - w + 1); M[5] = gtex1(plane, n, il + 1); D[5] = gtex1(plane, n, il + w + 1);
+        }
+        float hv[4];
+        float2 gv[4];
+        // two pixels at a time on 2-vectors, no per-pixel branches
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+#define HESS_V2(A, K) ((v2f){A[(K)], A[(K) + 1]})
+          const v2f v11 = HESS_V2(U, j), v12 = HESS_V2(U, j + 1), v13 = HESS_V2(U, j + 2);
+          const v2f v21 = HESS_V2(M, j), v22 = HESS_V2(M, j + 1), v23 = HESS_V2(M, j + 2);
+          const v2f v31 = HESS_V2(D, j), v32 = HESS_V2(D, j + 1), v33 = HESS_V2(D, j + 2);
+#undef HESS_V2
+          const v2f Lxx = v2_fma(v2_splat(-2.0f), v22, v21) + v23;   // ProgramCU.cu:536
+          const v2f Lyy = v2_fma(v2_splat(-2.0f), v22, v12) + v32;   // :537
+          const v2f Lxy = (v13 - v11 + v31 - v33) * v2_splat(0.25f);  // :538
+          const v2f dh = v2_fma(Lxx, Lyy, -(Lxy * Lxy)) * v2_splat(a.norm_src);  // :553
+          hv[j] = dh.x; hv[j + 1] = dh.y;
+          if (want_got) {
+            const v2f dx = v23 - v21, dy = v32 - v12;                 // :556-557
+            const v2f gradient = v2_splat(0.5f) * __builtin_elementwise_sqrt(v2_fma(dx, dx, dy * dy));
+            const v2f th = dm_atan2f_x2(dy, dx);
+            gv[j].x = gradient.x;     gv[j].y = (gradient.x == 0.0f) ? 0.0f : th.x;
+            gv[j + 1].x = gradient.y; gv[j + 1].y = (gradient.y == 0.0f) ? 0.0f : th.y;
+          }
+        }
+        const long long o = img * (long long)w * h + idx;
+        *reinterpret_cast<float4*>(a.deth_src + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (want_got) {
+          float2* gp = a.got_src + o;
+          *reinterpret_cast<float4*>(gp) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
+          *reinterpret_cast<float4*>(gp + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
         }
       }
     }
