@@ -332,10 +332,6 @@ __device__ __forceinline__ float dm_expf_inrange(float x) {
 
 typedef const __attribute__((address_space(1))) char* GlobalBytes;  // byte pointer into global memory (HBM)
 typedef float dfloat2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 load_global_float2(GlobalBytes p) {
-  const dfloat2 v = *(const __attribute__((address_space(1))) dfloat2*)p;
-  return make_float2(v.x, v.y);
-}
 
 // N consecutive iterations of a lane of the descriptor kernel: window coordinates, window test, gathered (gradient, theta)
 template <int N_>
@@ -410,11 +406,15 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     // registers so that a gather is `scalar base + 32-bit lane offset`
     const unsigned long long gpa = (unsigned long long)(reinterpret_cast<const float2*>(got) + og.got_off +
                                                         ((long long)(l - 1) * g.B + b) * og.plane);
-    // (rebuilt as a GLOBAL address-space pointer: from a generic one the compiler emits flat_load, which also
-    // counts as an LDS operation and would make every wait for the coefficient table wait for the gathers too)
+    // and gather through a buffer resource over the plane: `resource + 32-bit byte offset`, no 64-bit address
+    // arithmetic per sample, and an offset outside the plane reads 0 instead of faulting.  (A generic pointer here
+    // made the compiler emit flat_load, which also counts as an LDS operation: every wait for the coefficient
+    // table then waited for the gathers too.)
     const GlobalBytes gp = (GlobalBytes)(
         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gpa >> 32)) << 32) |
         (unsigned)__builtin_amdgcn_readfirstlane((int)(gpa & 0xFFFFFFFFull)));
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)gp, 0, __builtin_amdgcn_readfirstlane(og.plane * 8), 0x00020000 /* raw 32-bit data, gfx9 family */);
     const int width = og.wa, height = og.h;
 
     // un-mirrored orientation handed to the kernel (PyramidCU.cpp:764,791; A.1 of SURVEY)
@@ -500,7 +500,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         ck.nx[u] = fmaf(crspt, dx, srspt * dy);
         ck.ny[u] = fmaf(crspt, dy, -(srspt * dx));
         ck.in[u] = (yf <= ymax) & (fabsf(ck.nx[u]) < 1.0f) & (fabsf(ck.ny[u]) < 1.0f);
-        ck.cc[u] = load_global_float2(gp + (ck.in[u] ? goff : 0u));
+        const dfloat2 gv = __builtin_amdgcn_raw_buffer_load_b64(grsrc, (int)(ck.in[u] ? goff : 0u), 0, 0);
+        ck.cc[u] = make_float2(gv.x, gv.y);
         if (!NARROW) {
           const bool wrap = xf > xwrap;
           xf += wrap ? 4.0f - fnxs : 4.0f;
