@@ -196,7 +196,7 @@ def main():
             },
         }
         if prof is not None:
-            roofs = rooflines(prof, roof_steps, timed_keys)
+            roofs = rooflines(prof, roof_steps, timed_keys, B)
             ranked = sorted(roofs, key=lambda r: -r["ms_per_step"])
             if ranked:
                 out["roofline"] = ranked[0]
@@ -249,7 +249,7 @@ def host_legs(ctxs, nctx, imgs, B, args, run_steps, fence, torch):
     }
 
 
-def rooflines(prof, steps, timed_keys):
+def rooflines(prof, steps, timed_keys, images):
     """Roofline entries of the two heavy kernels from the single-stream profile leg."""
     import numpy as np
 
@@ -266,6 +266,13 @@ def rooflines(prof, steps, timed_keys):
             "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"], 1),
             "launches": g["launches"], "ms_per_step": round(g["ms"] / steps, 4),
         })
+        gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
+        if gi:
+            rate = gi * images * steps / (g["ms"] * 1e-3) / 1e9
+            out[-1]["valu"] = {"bound": "valu", "achieved": round(rate, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
+                               "frac": round(rate / VALU_PEAK_GINST, 4), "instructions_per_image": gi,
+                               "source": "SQ_INSTS_VALU of the PMC pass in profiles/gauss_traffic.json x images of this run "
+                                         "(about half are packed-FP32 or division/sqrt helper instructions that issue at half rate or less)"}
     d = prof["descriptor"]
     if d["launches"]:
         # algorithmic bytes of one launch (per output feature): the rotated 5x5-cell footprint of side

@@ -24,6 +24,10 @@ def main():
     g = bench["roofline"] if bench["roofline"]["kernel"].startswith("gauss") else bench["roofline_secondary"]
     traffic["algorithmic_bytes_per_launch"] = g["algorithmic_bytes_per_launch"]
     traffic["source"] = f"profiles/{tag}_* (tools/profile_round.sh {tag})"
+    # vector instructions of all Gaussian launches per image: the SQ pass runs 3 steps (--steps 2 --warmup 1) of one batch
+    batch = bench["config"]["images_per_gpu_per_step"]
+    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith("gauss_kernel"))
+    traffic["valu_insts_per_image"] = round(gv / (3 * batch), 1)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
     r = rows["descriptor_kernel"]
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]

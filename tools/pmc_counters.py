@@ -48,7 +48,7 @@ def main():
     for n in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
         x = agg[n]
         per = {c: x[c] / max(1, len(launches[n][c])) for c in order if c in x}
-        nl = max(len(v) for v in launches[n].values())
+        nl = min(len(v) for v in launches[n].values())  # dispatches of ONE pass (SQ_WAVES is collected in both)
         waves = per.get("SQ_WAVES", 0.0)
         row = [n, nl] + [f"{per.get(c, float('nan')):.5g}" for c in order]
         row += [f"{per.get('SQ_INSTS_VALU', 0) / waves:.5g}" if waves else "", f"{per.get('SQ_INSTS_LDS', 0) / waves:.5g}" if waves else ""]
