@@ -75,8 +75,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     # HESS_BENCH_FORCE_DIST=1 runs the RCCL gather path with a single rank (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("HESS_BENCH_FORCE_DIST") == "1"
+    json_fd = None
     if use_dist:
         import torch.distributed as tdist
+
+        # RCCL and gloo print banners on stdout when their communicators come up; the contract is ONE JSON line on
+        # rank 0's stdout, so everything but that line goes to stderr from here on
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group(backend="nccl", device_id=dev)
@@ -209,7 +216,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["parity_checked"] = parity_check(imgs[0], timed_k0, timed_d0)
             out["cpu_baseline"] = cpu_baseline(imgs[:min(nd, 4)])
-        print(json.dumps(out), flush=True)
+        if json_fd is None:
+            print(json.dumps(out), flush=True)
+        else:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     for c in ctxs:
         c.close()
     if use_dist:
