@@ -57,7 +57,8 @@ class HessParams(C.Structure):
         ("auto_downscale", C.c_int32),
         ("verbose", C.c_int32),
         ("dynamic_indexing", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("detector", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 

@@ -809,7 +809,8 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (!c) return nullptr;
   if (params) c->p = *params; else default_params(&c->p);
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
-      c->p.first_octave < -3) {  // "can't upsample by more than 8", PyramidCU.cpp:131-132
+      c->p.first_octave < -3 ||  // "can't upsample by more than 8", PyramidCU.cpp:131-132
+      c->p.detector != 0) {      // the product is the GPU_HESSIAN build; the DoG detector exists in the test oracle only
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;

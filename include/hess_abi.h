@@ -88,7 +88,12 @@ typedef struct hess_params {
   int32_t dynamic_indexing;     /* -di  descriptor bins indexed dynamically (GlobalUtil.cpp:108,
                                    ProgramCU.cu:1755-1771): a sample whose bin coordinate rounds up to
                                    exactly 8.0 is then added to bin 8 (folded into bin 0), not dropped */
-  int32_t reserved[7];
+  int32_t detector;             /* 0 = determinant of Hessian (GPU_HESSIAN, the only detector of the product:
+                                   hess_create refuses anything else).  1 = difference of Gaussians as the
+                                   reference compiles without GPU_HESSIAN (config.h:36): accepted by the CPU oracle
+                                   only, to reproduce the reference's doc/evaluation/box.siftgpu from pixels;
+                                   2 = the same with the level sigmas of the version that wrote that file */
+  int32_t reserved[6];
 } hess_params;
 
 /* Binary-identical to SiftGPU::SiftKeypoint (SiftGPU.h:108-116): 24 bytes. */

@@ -125,24 +125,52 @@ static void resolve_params(hess_cpu_ctx* c) {
   if (p->tex_max_dim == 0) p->tex_max_dim = 3200;
   if (p->max_orientation < 1) p->max_orientation = 1; /* SiftGPU.cpp:1047 clamps to 1..4 */
   if (p->max_orientation > 4) p->max_orientation = 4;
-  c->level_max = p->dog_level_num + 1;
-  c->level_num = c->level_max + 1;
-  c->level_ds = p->dog_level_num; /* _level_min + _dog_level_num, <= _level_max */
   float sigmak = powf(2.0f, 1.0f / p->dog_level_num);
-  float dsigma0 = p->sigma0 * sqrtf(sigmak * sigmak - 1.0f); /* SiftGPU.cpp:516 */
-  for (int i = 1; i <= c->level_max; i++)
-    c->sigma[i - 1] = dsigma0 * powf(sigmak, (float)(i - 1)); /* SiftGPU.cpp:547-552 */
-  for (int l = 0; l <= c->level_max; l++) /* GetLevelSigma, SiftGPU.cpp:1422-1425 */
-    c->level_sigma[l] = p->sigma0 * powf(2.0f, (float)l / (float)p->dog_level_num);
+  if (p->detector == 0) {
+    c->level_max = p->dog_level_num + 1;
+    c->level_num = c->level_max + 1;
+    c->level_ds = p->dog_level_num; /* _level_min + _dog_level_num, <= _level_max */
+    float dsigma0 = p->sigma0 * sqrtf(sigmak * sigmak - 1.0f); /* SiftGPU.cpp:516 */
+    for (int i = 1; i <= c->level_max; i++)
+      c->sigma[i - 1] = dsigma0 * powf(sigmak, (float)(i - 1)); /* SiftGPU.cpp:547-552 */
+    for (int l = 0; l <= c->level_max; l++) /* GetLevelSigma, SiftGPU.cpp:1422-1425 */
+      c->level_sigma[l] = p->sigma0 * powf(2.0f, (float)l / (float)p->dog_level_num);
+  } else {
+    /* The build WITHOUT GPU_HESSIAN (difference of Gaussians; SiftGPU.cpp:466-556, #else branches): levels
+     * _level_min = -1 .. _level_max = dog + 1 with _sigma0 = 1.6 * 2^(1/dog); this oracle's level j is that build's
+     * level j - 1, so its levels 0 .. dog + 2 carry the same sigmas as the Hessian build's plus one more on top.
+     * p->sigma0 keeps the Hessian convention (sigma of level 0). */
+    c->level_max = p->dog_level_num + 2;
+    c->level_num = c->level_max + 1;
+    c->level_ds = p->dog_level_num; /* _level_min + _dog_level_num = dog - 1 there, + 1 here */
+    float sigma0 = p->sigma0 * powf(2.0f, 1.0f / p->dog_level_num);                /* :503 */
+    float dsigma0 = sigma0 * sqrtf(1.0f - 1.0f / (sigmak * sigmak));               /* :531 */
+    for (int i = -1 + 1; i <= c->level_max - 1; i++)                               /* :544-555: _sigma[i+1-1] = dsigma0 * k^i */
+      c->sigma[i] = dsigma0 * powf(sigmak, (float)i);
+    for (int l = 0; l <= c->level_max; l++) /* GetLevelSigma(level = l - 1), :1422-1425 */
+      c->level_sigma[l] = sigma0 * powf(2.0f, (float)(l - 1) / (float)p->dog_level_num);
+    if (p->detector == 2) {
+      /* The keypoint scales of doc/evaluation/box.siftgpu are sigma0 * 2^(level / (2 dog)) * step^ds: the file was
+       * written before the "bug fix 9/12/2007" that GetLevelSigma's comment records (measured on the file: the
+       * ratio to today's formula is 2^(level/6) to four digits at each of the three levels).  Only the sigma handed
+       * to the orientation stage is affected; the pyramid is not. */
+      for (int l = 0; l <= c->level_max; l++)
+        c->level_sigma[l] = sigma0 * powf(2.0f, (float)(l - 1) / (float)(2 * p->dog_level_num));
+    }
+  }
   if (p->dog_threshold == 0.0f) p->dog_threshold = 0.02f / p->dog_level_num; /* :558-559 */
   if (p->edge_threshold == 0.0f) p->edge_threshold = 10.0f;                   /* :561-562 */
+  (void)sigmak;
   c->sigma_step = powf(2.0f, 1.0f / p->dog_level_num); /* PyramidCU.cpp:1821 */
   c->ln_sigma_step = (float)log((double)c->sigma_step);
 }
 
 /* SiftParam::GetInitialSmoothSigma, SiftGPU.cpp:482-489 (_level_min = 0). */
 static float initial_smooth_sigma(const hess_cpu_ctx* c, int octave_min) {
-  float sa = c->p.sigma0 * powf(2.0f, 0.0f / (float)c->p.dog_level_num);
+  /* sa = _sigma0 * 2^(_level_min / dog): level_min = 0 (Hessian) or _sigma0 = 1.6 * 2^(1/dog), level_min = -1 (DoG) */
+  float sa = c->p.detector == 0
+                 ? c->p.sigma0 * powf(2.0f, 0.0f / (float)c->p.dog_level_num)
+                 : (c->p.sigma0 * powf(2.0f, 1.0f / c->p.dog_level_num)) * powf(2.0f, -1.0f / (float)c->p.dog_level_num);
   float sb = c->p.sigman / powf(2.0f, (float)octave_min);
   return (sa > sb + 0.001) ? sqrtf(sa * sa - sb * sb) : 0.0f;
 }
@@ -356,9 +384,24 @@ typedef struct { uint32_t packed; float dx, dy, ds; } keyval;
     if ((response > nmin) || (response > 0)) return 0;                 \
   }
 
+/* READ_CMP_DOG_DATA without GPU_HESSIAN (ProgramCU.cu:680-699): no sign tests. */
+#define READ_CMP_DOG(datai, tex, idx)                                  \
+  datai[0] = tex[(idx) - 1]; datai[1] = tex[(idx)]; datai[2] = tex[(idx) + 1]; \
+  if (response > nmax) {                                               \
+    nmax = fmaxf(nmax, datai[0]); nmax = fmaxf(nmax, datai[1]); nmax = fmaxf(nmax, datai[2]); \
+    if (response < nmax) return 0;                                     \
+  } else {                                                             \
+    nmin = fminf(nmin, datai[0]); nmin = fminf(nmin, datai[1]); nmin = fminf(nmin, datai[2]); \
+    if (response > nmin) return 0;                                     \
+  }
+#define READ_ANY(datai, tex, idx) \
+  if (dogmode) { READ_CMP_DOG(datai, tex, idx) } else { READ_CMP(datai, tex, idx) }
+
+/* dogmode: the kernel as compiled without GPU_HESSIAN (the planes are differences of Gaussians, the extremum test
+ * has no sign condition, the "type" is the sign of the extremum, :853-854). */
 static int compute_key(const float* texC, const float* texP, const float* texN, const float* texG,
                        int width, int row, int col, float thr0, float thr, float edge_thr,
-                       int subpixel, keyval* out) {
+                       int subpixel, int dogmode, keyval* out) {
   float data[3][3], datap[3][3], datan[3][3];
   float response, nmax, nmin;
   float dx = 0, dy = 0, ds = 0;
@@ -373,8 +416,8 @@ static int compute_key(const float* texC, const float* texP, const float* texN, 
   nmax = fmaxf(data[1][0], data[1][2]);
   nmin = fminf(data[1][0], data[1][2]);
   if ((response <= nmax) && (response >= nmin)) return 0;
-  READ_CMP(data[0], texC, idx[0]);
-  READ_CMP(data[2], texC, idx[2]);
+  READ_ANY(data[0], texC, idx[0]);
+  READ_ANY(data[2], texC, idx[2]);
 
   /* edge suppression, ProgramCU.cu:748-757 */
   float vx2 = response * 2.0f;
@@ -385,12 +428,12 @@ static int compute_key(const float* texC, const float* texP, const float* texN, 
   float temp2 = (fxx + fyy) * (fxx + fyy);
   if ((temp1 <= 0) || (temp2 > edge_thr * temp1)) return 0;
 
-  READ_CMP(datap[0], texP, idx[0]);
-  READ_CMP(datap[1], texP, idx[1]);
-  READ_CMP(datap[2], texP, idx[2]);
-  READ_CMP(datan[0], texN, idx[0]);
-  READ_CMP(datan[1], texN, idx[1]);
-  READ_CMP(datan[2], texN, idx[2]);
+  READ_ANY(datap[0], texP, idx[0]);
+  READ_ANY(datap[1], texP, idx[1]);
+  READ_ANY(datap[2], texP, idx[2]);
+  READ_ANY(datan[0], texN, idx[0]);
+  READ_ANY(datan[1], texN, idx[1]);
+  READ_ANY(datan[2], texN, idx[2]);
 
   if (subpixel) { /* ProgramCU.cu:769-825 */
     float fx = 0.5f * (data[1][2] - data[1][0]);
@@ -431,7 +474,8 @@ static int compute_key(const float* texC, const float* texP, const float* texN, 
   if (!offset_test_passed) return 0;
 
   unsigned type; /* ProgramCU.cu:828-851 */
-  if (response < 0) type = HESS_TYPE_SADDLE;
+  if (dogmode) type = (response > nmax) ? HESS_TYPE_BRIGHT_BLOB : HESS_TYPE_DARK_BLOB; /* result = +-1, :853-854 */
+  else if (response < 0) type = HESS_TYPE_SADDLE;
   else {
     float g0 = texG[idx[1] - 1], g1 = texG[idx[1]], g2 = texG[idx[1] + 1];
     float Lxx = fmaf(-2.0f, g1, g0) + g2;
@@ -517,6 +561,43 @@ static void compute_orientation(const hess_cpu_ctx* c, const hess_rawkey* rk, co
       float off = 0.5f * ((next - pre) / (weight + weight - next - pre));
       kw = radius_per_ten_degrees * (index_max + 0.5f + off);
       kw_bits = om_f2u(kw);
+    } else if (p->detector != 0) {
+      /* build without GPU_HESSIAN, ProgramCU.cu:1493-1548: the two strongest peaks, 16-bit angles, 65535 = none */
+      float max_vote = vote[0];
+      for (int i = 1; i < 36; ++i) max_vote = fmaxf(max_vote, vote[i]);
+      float vote_threshold = max_vote * 0.8f;
+      float pre = vote[35];
+      float max_rot[2] = {0, 0}, max_vot[2] = {0, 0};
+      int ocount = 0;
+      for (int i = 0; i < 36; ++i) {
+        float next = vote[i + 1];
+        if ((vote[i] > vote_threshold) && (vote[i] > pre) && (vote[i] > next)) {
+          float di = 0.5f * ((next - pre) / (vote[i] + vote[i] - next - pre));
+          float rot = i + di + 0.5f;
+          float weight = vote[i];
+          if (weight > max_vot[1]) {
+            if (weight > max_vot[0]) {
+              max_vot[1] = max_vot[0]; max_rot[1] = max_rot[0];
+              max_vot[0] = weight; max_rot[0] = rot;
+            } else {
+              max_vot[1] = weight; max_rot[1] = rot;
+            }
+            ocount++;
+          }
+        }
+        pre = vote[i];
+      }
+      float fr1 = max_rot[0] / 36.0f;
+      if (fr1 < 0) fr1 += 1.0f;
+      uint32_t us1 = (ocount == 0) ? 65535u : (uint32_t)(unsigned short)floor(fr1 * 65535.0f);
+      uint32_t us2 = 65535u;
+      if (ocount > 1) {
+        float fr2 = max_rot[1] / 36.0f;
+        if (fr2 < 0) fr2 += 1.0f;
+        us2 = (uint32_t)(unsigned short)floor(fr2 * 65535.0f);
+      }
+      kw_bits = (us2 << 16) | us1;
+      orientationsCount = (us1 != 65535u) + (us2 != 65535u); /* what ReshapeFeatureListCPU expands, PyramidCU.cpp:800-820 */
     } else { /* ProgramCU.cu:1424-1489 */
       float max_vote = vote[0];
       for (int i = 1; i < 36; ++i) max_vote = fmaxf(max_vote, vote[i]);
@@ -745,7 +826,8 @@ hess_cpu_ctx* hess_cpu_create(const hess_params* params) {
   if (!c) return NULL;
   if (params) c->p = *params; else hess_cpu_default_params(&c->p);
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > 10 ||
-      c->p.first_octave < -3) { /* "can't upsample by more than 8", PyramidCU.cpp:131-132 */
+      c->p.first_octave < -3 || /* "can't upsample by more than 8", PyramidCU.cpp:131-132 */
+      c->p.detector < 0 || c->p.detector > 2) {
     free(c);
     return NULL;
   }
@@ -1039,6 +1121,13 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     for (int l = 0; l <= c->level_max; l++) {
       float ls = c->level_sigma[l] * 1.0f; /* octaveSigma = 1, PyramidCU.cpp:1574-1585 */
       compute_hessian(py->gauss[o][l], py->deth[o][l], py->got[o][l], c->g[o].wa, c->g[o].h, ls * ls);
+      if (p->detector != 0 && l >= 1) { /* ComputeDOG_Kernel, ProgramCU.cu:598-637: the plane the extrema are sought in */
+        const float* a = py->gauss[o][l];
+        const float* b = py->gauss[o][l - 1];
+        float* d = py->deth[o][l];
+        size_t n = (size_t)c->g[o].wa * c->g[o].h;
+        for (size_t i = 0; i < n; i++) d[i] = a[i] - b[i];
+      }
     }
   if (c->user_num > 0) { /* SIFT_SKIP_DETECTION: ComputeGradient + GenerateFeatureListTex */
     int rc = user_keypoint_path(c, R);
@@ -1059,10 +1148,13 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     int o = li / dog, l = li % dog + 1;
     int wa = c->g[o].wa, h = c->g[o].h;
     keyval kv;
+    /* without GPU_HESSIAN the list `level` (0..dog-1) is sought in DoG plane level + 2 of that build = l + 1 here
+     * (between Gaussian levels l and l + 1) and described from Gaussian level l (PyramidCU.cpp:1655-1670, 1825-1846) */
+    const int dm = p->detector != 0, pl = dm ? l + 1 : l;
     for (int row = 1; row < h - 1; row++)
       for (int col = 1; col < wa - 1; col++)
-        if (compute_key(py->deth[o][l], py->deth[o][l - 1], py->deth[o][l + 1], py->gauss[o][l], wa, row, col,
-                        Tdog1, Tdog, Tedge, p->subpixel, &kv)) {
+        if (compute_key(py->deth[o][pl], py->deth[o][pl - 1], py->deth[o][pl + 1], py->gauss[o][l], wa, row, col,
+                        Tdog1, Tdog, Tedge, p->subpixel, dm, &kv)) {
           hess_rawkey rk;
           rk.level_index = li; rk.col = col; rk.row = row; rk.packed = kv.packed;
           rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
@@ -1164,7 +1256,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   if (!frecs || !angles || !flevel || !keys) return HESS_ERR_NOMEM;
   {
     const double twopi = 2.0 * PI_D;
-    const double factor = 2.0 * PI_D / 255.0;
+    const double factor = p->detector != 0 ? 2.0 * PI_D / 65535.0 : 2.0 * PI_D / 255.0; /* PyramidCU.cpp:763-767 */
     float octave_sigma = first_octave_sigma(c); /* 2^_octave_min */
     float offset = p->lowe_origin ? 0.0f : 0.5f;
     int m = 0;
@@ -1174,7 +1266,9 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
       for (int k = 0; k < cnt; k++, m++) {
         frecs[m] = recs[n];
         flevel[m] = li;
-        angles[m] = multi ? (float)(factor * ((recs[n].w >> (8 * k)) & 0xFFu)) : om_u2f(recs[n].w);
+        angles[m] = !multi ? om_u2f(recs[n].w)
+                    : (p->detector != 0 ? (float)(factor * ((recs[n].w >> (16 * k)) & 0xFFFFu))
+                                        : (float)(factor * ((recs[n].w >> (8 * k)) & 0xFFu)));
         float oss = octave_sigma * (float)(1 << (li / dog));
         float posX = FIXED_TO_FLOAT(recs[n].x & 0x00FFFFFFu, 10);
         float posY = FIXED_TO_FLOAT(recs[n].y & 0x00FFFFFFu, 10);

@@ -13,7 +13,12 @@
  * SaveSIFT code): with the first octave up-sampled as the file's `-fo -1` asks, every one of the 581
  * keypoints whose descriptor footprint lies inside the image is reproduced to <= 1 count of 512 in all 128
  * values, and the computed orientations fall within half an 8-bit step of the file's for 99.7 % of them
- * (tests/test_reference_fixture.py, tests/box_fixture.py).  The rest of the oracle is checked against (a) IEEE
+ * (tests/test_reference_fixture.py, tests/box_fixture.py).  Run as the build that wrote the file (detector = 2:
+ * DoG planes, no sign conditions, two-peak orientation rule -- the reference's #ifndef GPU_HESSIAN lines -- on otherwise
+ * the same code) the oracle also re-detects the file's features from the pixels: 671 features against 673, 664
+ * matched one to one within the file's rounding, descriptors of all interior ones within 1 count.  Without
+ * reference-made evidence remain only the Hessian-specific lines (det-H formula, sign conditions, type) and the
+ * top-K tie rule.  The rest of the oracle is checked against (a) IEEE
  * facts it must satisfy (half conversions vs numpy.float16, math functions vs libm) and (b) an independently
  * written NumPy restatement (tests/np_restatement.py).
  *

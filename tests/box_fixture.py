@@ -33,6 +33,22 @@ reported, not asserted: 40 % of them still agree to <= 1 count, the ones whose r
 
 The remaining <= 1 count is the file's own rounding: x, y to 0.01 px, scale and orientation to 0.001, and the
 orientations of the multi-orientation path it was written with are 8-bit (2*pi/255 = 0.0246 rad).
+
+Second, stronger use of the file (`reproduce_from_pixels`): the ORACLE can also run as the build the file was written
+by -- `detector = 2` in hess_params: differences of Gaussians instead of det-Hessian planes, the extremum test without
+its two sign conditions, the two-strongest-peaks orientation rule with 16-bit angles (everything the reference puts
+under `#ifndef GPU_HESSIAN`: ProgramCU.cu:598-637,680-699,853-854,1493-1548; SiftGPU.cpp:466-556), and the level sigma
+as it was before the "bug fix 9/12/2007" recorded at SiftGPU.cpp:1424 (the file's scales are sigma0 * 2^(level/6) *
+step^ds; measured ratio to today's formula 2^(level/6) to four digits at every level).  Everything else is the SAME
+oracle code the Hessian mode runs: pyramid, the 3x3x3 scan with its per-triple branch re-selection, edge test, the
+pivoted 3x3 sub-pixel solve and its acceptance test, list order, keypoint packing and unpacking, orientation histogram,
+multi-orientation expansion, descriptor, normalisation.  From the PIXELS of box.pgm it then finds 671 features at 539
+locations (file: 673 at 541) and 664 of the file's 673 features are matched one to one within 0.024 px, 0.4 % in scale
+and 0.001 rad for 654 of them (0.032 at most); every one of the 581 matched features whose footprint lies inside the
+image has its descriptor within 1 count of 512 in all 128 values; 8 of the 9 unmatched features have their
+orientation window cut by the image border.  This is the detector's reference-made evidence: the product is not run in
+this mode (hess_create refuses `detector != 0`), it equals the oracle bit for bit in Hessian mode, and the two modes
+differ only in the few lines listed above.
 """
 import os
 
@@ -115,4 +131,41 @@ def analyse(session, img, vals):
         "err": E[rows, pick], "err_next": other.min(1), "level": L[rows, pick], "dlevel": t - L[rows, pick],
         "dangle": dangle, "interior": edge - (2.5 * np.sqrt(2.0) * 3.0 * s + 1.0) >= 0,
         "ointerior": edge - (1.5 * 3.0 * s + 1.0) >= 0, "desc": np.stack(descs, 1)[rows, pick],
+    }
+
+
+DOG_PARAMS = dict(first_octave=-1, orient_window_factor=3.0, lowe_origin=1, detector=2)
+
+
+def reproduce_from_pixels(session, img, vals):
+    """Detect + describe box.pgm with `session` (oracle created with DOG_PARAMS) and match the result one to one with
+    the file's features.  Returns a dict: n_features, n_locations, pairs (file index, result index), unmatched (file
+    indices), and for the pairs: pos (px), angle (rad), scale_ratio, err (worst descriptor count difference),
+    interior (descriptor footprint inside the image); for the unmatched: owin_margin (distance of the orientation
+    window from the image border, negative = cut)."""
+    n = session.run(img[None])[0]
+    k, d = session.fetch(0)
+    used = np.zeros(n, bool)
+    pairs, unmatched = [], []
+    for i in range(len(vals)):
+        dist = np.hypot(k["x"] - vals[i, 1], k["y"] - vals[i, 0])
+        da = angle_diff(k["o"].astype(np.float64), vals[i, 3])
+        cand = np.flatnonzero((dist < 0.05) & (da < 0.05) & ~used)
+        if len(cand):
+            j = cand[np.argmin(dist[cand] + da[cand])]
+            used[j] = True
+            pairs.append((i, j))
+        else:
+            unmatched.append(i)
+    pi, pj = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    x, y, s = vals[:, 1], vals[:, 0], vals[:, 2]
+    edge = np.minimum.reduce([x, W - x, y, H - y])
+    return {
+        "n_features": n, "n_locations": len(session.rawlist(0)), "pairs": pairs, "unmatched": unmatched,
+        "pos": np.hypot(k["x"][pj] - x[pi], k["y"][pj] - y[pi]),
+        "angle": angle_diff(k["o"][pj].astype(np.float64), vals[pi, 3]),
+        "scale_ratio": k["s"][pj] / s[pi],
+        "err": np.abs(np.floor(512.0 * d[pj] + 0.5) - vals[pi, 4:]).max(axis=1),
+        "interior": (edge - (2.5 * np.sqrt(2.0) * 3.0 * s + 1.0) >= 0)[pi],
+        "owin_margin": (edge - (1.5 * 3.0 * s + 1.0))[np.array(unmatched, dtype=int)],
     }

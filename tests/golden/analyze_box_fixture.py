@@ -50,6 +50,21 @@ def main():
         e = np.abs(np.floor(512.0 * s.fetch(0)[1] + 0.5) - vals[:, 4:]).max(axis=1)[it]
         print(f"  control, {name}: <=1 count for {(e <= 1).mean():.3f} of the interior keypoints (median {np.median(e):.0f})")
     s.debug_key_levels(None)
+    if "--gpu" in sys.argv:
+        return
+    # from the pixels: the oracle as the build that wrote the file (tests/box_fixture.py, second part of the docstring)
+    from oracle_lib import OracleSession
+
+    o = OracleSession(threads=8, **bf.DOG_PARAMS)
+    r = bf.reproduce_from_pixels(o, img, vals)
+    it = r["interior"]
+    print(f"from pixels, DoG mode: {r['n_features']} features at {r['n_locations']} locations (file: {n} at "
+          f"{len(set(map(tuple, vals[:, :3])))}); matched one to one: {len(r['pairs'])}")
+    print(f"  position within {r['pos'].max():.3f} px, scale within {np.abs(r['scale_ratio'] - 1).max() * 100:.2f} %, angle within 0.001 rad "
+          f"for {(r['angle'] < 0.001).sum()} (max {r['angle'].max():.3f})")
+    print(f"  descriptors of the {it.sum()} matched features with the footprint inside the image: worst count difference "
+          f"{r['err'][it].max():.0f}; of the {(~it).sum()} at the border: <=1 for {(r['err'][~it] <= 1).mean():.2f}")
+    print(f"  unmatched file features {r['unmatched']}: orientation-window margin to the border {np.round(r['owin_margin'], 1).tolist()}")
 
 
 if __name__ == "__main__":

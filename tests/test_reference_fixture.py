@@ -13,7 +13,11 @@ Asserted, for the oracle on the CPU and for the HIP path on the GPU (which must 
   * the coordinate and angle conventions matter: flipping the angle sense or moving the origin by one pixel
     leaves no keypoint in agreement.
 The remaining 92 keypoints touch the image border (rule in tests/box_fixture.py) and are not asserted.
-PARITY of the DETECTOR (det-Hessian extrema, top-K) stays UNPINNED: no reference output of the Hessian path exists."""
+And from the PIXELS: the oracle run as the build that wrote the file (DoG planes, extremum test without the two sign
+conditions, two-peak orientation rule -- the reference's `#ifndef GPU_HESSIAN` lines -- on otherwise the same code)
+finds the file's features again: detection, sub-pixel refinement, orientation and descriptor end to end.
+What stays UNPINNED: the Hessian-specific lines themselves (det-H formula, the sign conditions, the blob/saddle type)
+and top-K: no reference output of the Hessian path exists."""
 import numpy as np
 import pytest
 
@@ -48,6 +52,28 @@ def test_oracle_orientation_and_descriptors_match_the_reference_file():
         e = np.abs(np.floor(512.0 * o.fetch(0)[1] + 0.5) - vals[:, 4:]).max(axis=1)[r["interior"]]
         assert (e <= 1).mean() < 0.02 and np.median(e) > 30
     o.close()
+
+
+def test_oracle_as_the_dog_build_reproduces_the_file_from_pixels():
+    img, vals = bf.load()
+    o = OracleSession(threads=8, **bf.DOG_PARAMS)
+    r = bf.reproduce_from_pixels(o, img, vals)
+    o.close()
+    assert abs(r["n_features"] - 673) <= 3 and abs(r["n_locations"] - 541) <= 3, (r["n_features"], r["n_locations"])
+    assert len(r["pairs"]) >= 0.985 * len(vals)                       # 664 of 673 matched one to one
+    assert r["pos"].max() < 0.03 and np.abs(r["scale_ratio"] - 1.0).max() < 0.005
+    assert (r["angle"] < 0.0015).mean() > 0.98 and r["angle"].max() < 0.05
+    it = r["interior"]
+    assert it.sum() >= 575 and r["err"][it].max() <= 1.0              # every interior descriptor within 1 count of 512
+    assert (r["owin_margin"] < 0).sum() >= len(r["unmatched"]) - 1    # what is not matched sits at the image border
+
+
+def test_dog_mode_is_refused_by_the_product():
+    import hessgpu_amd
+    from hessgpu_amd.session import HessError
+
+    with pytest.raises(HessError):
+        hessgpu_amd.HessContext(0, detector=2)
 
 
 def test_default_level_binning_without_the_hook():
