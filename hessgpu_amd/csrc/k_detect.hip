@@ -796,30 +796,47 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const 
     __syncthreads();
   }
   const int cut = s_cut, need = s_need;
-  // ordered compaction: keep key > cut, and the first `need` entries with key == cut
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    int keep = 0, tie = 0;
-    RawKey rk;
-    if (i < n) {
-      rk = in[i];
-      if (cut < 0) keep = 1;
-      else {
-        const int key = (int)((rk.packed >> 16) & 0x7fffu);
-        if (key > cut) keep = 1;
-        else if (key == cut) tie = 1;
+  // ordered compaction: keep key > cut, and the first `need` entries with key == cut.  A thread takes four
+  // consecutive entries per pass (list order = thread order, then entry order), so a 16 k list needs four passes of
+  // two block scans instead of sixteen.
+  constexpr int IT = 4;
+  for (int base = 0; base < n; base += 1024 * IT) {
+    const int i0 = base + tid * IT;
+    RawKey rk[IT];
+    int keep[IT], tie[IT], nt = 0;
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+      keep[j] = 0; tie[j] = 0;
+      if (i0 + j < n) {
+        rk[j] = in[i0 + j];
+        if (cut < 0) keep[j] = 1;
+        else {
+          const int key = (int)((rk[j].packed >> 16) & 0x7fffu);
+          if (key > cut) keep[j] = 1;
+          else if (key == cut) tie[j] = 1;
+        }
       }
+      nt += tie[j];
     }
     int etie, ekeep0, ttie, tkeep0;
-    block_scan2(tie, 0, &etie, &ekeep0, &ttie, &tkeep0, lds);
-    if (tie && (s_ties + etie) < need) keep = 1;
-    int ekeep, edummy, tkeep, tdummy;
-    block_scan2(keep, 0, &ekeep, &edummy, &tkeep, &tdummy, lds);
-    if (keep) {
-      const int pos = s_kept + ekeep;
-      if (pos < cap_sel) out[pos] = rk;
-      atomicAdd(&lc[rk.level_index], 1);
+    block_scan2(nt, 0, &etie, &ekeep0, &ttie, &tkeep0, lds);
+    int nk = 0, tseen = s_ties + etie;
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+      if (tie[j] && tseen < need) keep[j] = 1;
+      tseen += tie[j];
+      nk += keep[j];
     }
+    int ekeep, edummy, tkeep, tdummy;
+    block_scan2(nk, 0, &ekeep, &edummy, &tkeep, &tdummy, lds);
+    int pos = s_kept + ekeep;
+#pragma unroll
+    for (int j = 0; j < IT; j++)
+      if (keep[j]) {
+        if (pos < cap_sel) out[pos] = rk[j];
+        atomicAdd(&lc[rk[j].level_index], 1);
+        pos++;
+      }
     __syncthreads();
     if (tid == 0) { s_ties += ttie; s_kept += tkeep; }
     __syncthreads();
