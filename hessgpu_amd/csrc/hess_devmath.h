@@ -136,6 +136,17 @@ __device__ __forceinline__ void dm_sincosf(float a, float* s, float* c) {
   *c = cv;
 }
 
+// b / 255.0f for an integer-valued 0 <= b <= 255 (u8 luminance -> [0,1], GLTexImage.cpp:828), correctly rounded
+// without the division sequence: q0 = b * fl(1/255) is within an ulp, the residual b - 255*q0 is exact in one fma,
+// and one more fma adds the correction.  Equal to the IEEE quotient for all 256 inputs (checked exhaustively on the
+// host in tests/test_oracle_math.py and on the device in tests/test_gpu_parity.py); 3 instructions instead of 11.
+__device__ __forceinline__ float dm_u8_unit(float b) {
+  const float r = 1.0f / 255.0f;  // constant-folded: fl(1/255)
+  const float q0 = b * r;
+  const float e = fmaf(q0, -255.0f, b);
+  return fmaf(e, r, q0);
+}
+
 // binary32 -> binary16 bits, round to nearest even (__float2half_rn, ProgramCU.cu:865).
 __device__ __forceinline__ uint32_t dm_f2h(float f) {
   uint32_t x = f2u(f);

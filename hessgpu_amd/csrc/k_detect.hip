@@ -859,6 +859,7 @@ __global__ void math_probe_kernel(int which, const float* a, const float* b, flo
     case 5: r = dm_h2f((uint32_t)a[i]); break;
     case 6: r = a[i] / b[i]; break;
     case 7: r = sqrtf(a[i]); break;
+    case 8: r = dm_u8_unit(a[i]); break;
     default: break;
   }
   out[i] = r;

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
     if (U8) {
       const uint8_t* row = a.src_u8 + img * a.src_img_stride + (long long)y * a.src_pitch;
       const uchar4 b = *reinterpret_cast<const uchar4*>(row + xs);
-      stage[it] = make_float4((float)b.x / 255.0f, (float)b.y / 255.0f,   // GLTexImage.cpp:828
-                              (float)b.z / 255.0f, (float)b.w / 255.0f);
+      stage[it] = make_float4(dm_u8_unit((float)b.x), dm_u8_unit((float)b.y),   // p / 255.0f, GLTexImage.cpp:828
+                              dm_u8_unit((float)b.z), dm_u8_unit((float)b.w));
     } else {
       const float* row = a.src + img * a.src_img_stride + (long long)y * a.src_pitch;
       stage[it] = *reinterpret_cast<const float4*>(row + xs);

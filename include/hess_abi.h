@@ -230,7 +230,8 @@ float hess_matcher_last_ms(hess_matcher* m);   /* device time of the last match'
 const char* hess_matcher_last_error(hess_matcher* m);
 
 /* Test hook: evaluate one of the device's elementary functions (hess_devmath.h) on n inputs.
- * which: 0 exp(a) 1 atan2(a,b) 2 sin(a) 3 cos(a) 4 float->half bits 5 half bits->float 6 a/b 7 sqrt(a). */
+ * which: 0 exp(a) 1 atan2(a,b) 2 sin(a) 3 cos(a) 4 float->half bits 5 half bits->float 6 a/b 7 sqrt(a)
+ * 8 the u8 -> [0,1] conversion a/255 for integer a in 0..255. */
 int hess_math_probe(hess_ctx* ctx, int which, const float* a, const float* b, float* out, int n);
 
 #ifdef __cplusplus

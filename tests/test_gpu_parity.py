@@ -97,6 +97,9 @@ def test_math_functions_bit_exact(gpu_ctx_factory):
     num, den = rng.rand(20000).astype(np.float32), (rng.rand(20000) + 0.1).astype(np.float32)
     assert np.array_equal(g.math_probe(6, num, den), num / den)
     assert np.array_equal(g.math_probe(7, num), np.sqrt(num))
+    # u8 luminance -> [0,1]: the three-instruction form equals the IEEE quotient p / 255.0f for every byte value
+    byte = np.arange(256, dtype=np.float32)
+    assert np.array_equal(g.math_probe(8, byte).view(np.uint32), (byte / np.float32(255.0)).view(np.uint32))
 
 
 def test_parity_640_rgb_all_stages(gpu_ctx_factory):

@@ -74,3 +74,17 @@ def test_sincosf_abs_error():
     # __sincosf is a fast intrinsic (abs error ~2^-21.4 in [-pi,pi]); this model is tighter
     assert np.abs(gs - np.sin(a.astype(np.float64))).max() < 2.0e-7
     assert np.abs(gc - np.cos(a.astype(np.float64))).max() < 2.0e-7
+
+
+def test_u8_to_unit_three_instruction_form_is_the_ieee_quotient():
+    """The HIP kernels convert u8 luminance with q0 = b * fl(1/255); e = fma(q0, -255, b); q = fma(e, fl(1/255), q0)
+    (hess_devmath.h: dm_u8_unit) instead of the division the reference and the oracle write (GLTexImage.cpp:828).
+    Exhaustive check that the two agree bit for bit (also for the 16-bit form with 65535); the fused multiply-adds are
+    evaluated exactly in binary64 here (the products of these small integers fit) and rounded once."""
+    for top in (255.0, 65535.0):
+        b = np.arange(int(top) + 1, dtype=np.float32)
+        r = np.float32(1.0) / np.float32(top)
+        q0 = (b * r).astype(np.float32)
+        e = (q0.astype(np.float64) * -top + b.astype(np.float64)).astype(np.float32)
+        q = (e.astype(np.float64) * np.float64(r) + q0.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(q.view(np.uint32), (b / np.float32(top)).view(np.uint32))
