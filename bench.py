@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")
+    ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "
+                    "the headline workload uses the default (all 7 octaves of 1920x1080)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,7 +107,8 @@ def main():
     # Contexts used round-robin: while one batch's results travel to the host (and, for N > 1, are gathered over
     # RCCL), the next batches' kernels already run on the other contexts' streams.
     nctx = max(1, args.contexts)
-    ctxs = [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK)
+    ctxs = [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
+                                    octave_num=args.octaves)
             for _ in range(nctx)]
     for c in ctxs:
         c.reserve(W, H, B)
@@ -175,6 +178,8 @@ def main():
         pixels = float(world) * B * args.steps * W * H
         value = pixels / dt / 1e6
         workload = "1920x1080 synthetic blobs (tests/fixtures.py), default octaves/DoG levels, top-K=4096 [configs[1]]"
+        if args.octaves > 0:
+            workload += f" -- DEVELOPER RUN limited to {args.octaves} octaves, not the headline workload"
         if world > 1:
             workload = (f"batch of {B * world} synthetic 1920x1080 images sharded over {world} GPUs, {B} per GPU per step, "
                         "top-K=4096, RCCL gather of the feature lists to rank 0 [configs[3]: 64 images at 8 GPUs]")
