@@ -160,7 +160,7 @@ def main():
     # Legs outside the timed region (rank 0 alone reports them; every rank runs the device ones to stay in step).
     # Roofline leg: per-kernel hipEvent durations are only meaningful when kernels of different streams do not
     # overlap, so the events are recorded in a separate single-stream leg of the same run (same batch, one context).
-    prof, roof_steps = None, 0
+    prof, prof_dev, roof_steps = None, None, 0
     if not args.no_profile:
         c = ctxs[0]
         roof_steps = max(3, min(args.steps, 10))
@@ -170,6 +170,25 @@ def main():
             c.run_device(d_imgs.data_ptr(), B, H, W)
         prof = c.profile()
         c.profile_enable(False)
+        # The shipped descriptor launch also stores its 536 B per feature into pinned host memory (posted PCIe
+        # writes); alone on the device it then waits for the link.  The same leg on a context that delivers by a
+        # copy after the kernels shows the kernel's own duration.
+        saved = os.environ.get("HESS_HOST_DIRECT")
+        os.environ["HESS_HOST_DIRECT"] = "0"
+        cd = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
+                                     octave_num=args.octaves)
+        if saved is None:
+            del os.environ["HESS_HOST_DIRECT"]
+        else:
+            os.environ["HESS_HOST_DIRECT"] = saved
+        cd.reserve(W, H, B)
+        cd.run_device(d_imgs.data_ptr(), B, H, W)
+        cd.profile_enable(True)
+        cd.profile_reset()
+        for _ in range(roof_steps):
+            cd.run_device(d_imgs.data_ptr(), B, H, W)
+        prof_dev = cd.profile()
+        cd.close()
     host = None
     if world == 1 and not use_dist and not args.no_host_leg:
         host = host_legs(ctxs, nctx, imgs, B, args, run_steps, fence, torch)
@@ -208,7 +227,7 @@ def main():
             },
         }
         if prof is not None:
-            roofs = rooflines(prof, roof_steps, timed_keys, B)
+            roofs = rooflines(prof, roof_steps, timed_keys, B, prof_dev)
             ranked = sorted(roofs, key=lambda r: -r["ms_per_step"])
             if ranked:
                 out["roofline"] = ranked[0]
@@ -264,7 +283,7 @@ def host_legs(ctxs, nctx, imgs, B, args, run_steps, fence, torch):
     }
 
 
-def rooflines(prof, steps, timed_keys, images):
+def rooflines(prof, steps, timed_keys, images, prof_dev=None):
     """Roofline entries of the two heavy kernels from the single-stream profile leg."""
     import numpy as np
 
@@ -314,6 +333,17 @@ def rooflines(prof, steps, timed_keys, images):
             e["valu"] = {"bound": "valu", "achieved": round(rate, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
                          "frac": round(rate / VALU_PEAK_GINST, 4), "instructions_per_feature": insts,
                          "source": "SQ_INSTS_VALU of the PMC pass in profiles/descriptor_counters.json x features of this run"}
+        dd = (prof_dev or {}).get("descriptor")
+        if dd and dd["launches"]:
+            ddur = dd["ms"] * 1e-3 / dd["launches"]
+            e["without_host_mirror"] = {
+                "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(fbytes / ddur / 1e9, 1), "unit": "GB/s",
+                "note": "same launch on a context that delivers results by a copy after the kernels (HESS_HOST_DIRECT=0): "
+                        "the shipped launch also stores keypoints + descriptors into pinned host memory and, alone "
+                        "on the device, waits for PCIe",
+            }
+            if insts:
+                e["without_host_mirror"]["valu_frac"] = round(insts * nfeat / ddur / 1e9 / VALU_PEAK_GINST, 4)
         out.append(e)
     return out
 

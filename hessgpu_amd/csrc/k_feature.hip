@@ -521,8 +521,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     };
     auto stage_b = [&](const auto& ck) {
       constexpr int N = std::remove_reference_t<decltype(ck)>::N;
-#pragma unroll
-      for (int u = 0; u < N; u++) {
+      auto one = [&](int u) {
         const float nxn = fabsf(ck.nx[u]), nyn = fabsf(ck.ny[u]);
         const float dnx = ck.nx[u] + offx, dny = ck.ny[u] + offy;
         const float ww = dm_expf_inrange(-0.125f * fmaf(dnx, dnx, dny * dny));
@@ -547,6 +546,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         accumulate(c0, c1, c2, wt);
         mycol[fidx * DC_BIN_PITCH] = 0.0f;
         mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = 0.0f;
+      };
+#pragma unroll
+      for (int u = 0; u < N; u++) {
+        // The sixteen cells walk their boxes in step and have the same shape, so their misses coincide: in about
+        // one iteration of six no lane of the wavefront has a sample inside its window.  Such an iteration adds
+        // coefficient * 0 everywhere; skipping it changes no bit.
+        if (!__any(ck.in[u])) continue;
+        one(u);
       }
     };
     if (narrow) {  // degenerate scales only: one iteration at a time
