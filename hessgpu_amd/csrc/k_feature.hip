@@ -388,6 +388,50 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const int dim = dp.half_sift ? 64 : 128;
   const int mycell = lane >> 2, sub = lane & 3;
   float* const rows = &crow[wv][0];
+
+  // Host keypoint records (PyramidCU.cpp:866-906 / :1097-1137, host arithmetic): one thread per feature, 256 per
+  // workgroup, staged in LDS (the coefficient tables are not in use yet) and stored as contiguous 8-byte pieces --
+  // 24-byte records stored one by one from a lane of every wavefront reached the pinned host mirror as as many
+  // small PCIe writes and cost the kernel as much as the 512-byte descriptors did.
+  for (int f0 = blockIdx.x * 256; f0 < ftotal; f0 += gridDim.x * 256) {  // (uniform over the workgroup)
+    const int nrec = min(256, ftotal - f0);
+    uint32_t* const kst = reinterpret_cast<uint32_t*>(&crow[0][0]);
+    static_assert(sizeof(HostKeypoint) == 24 && 4 * DC_ROWS * 4 >= 256 * 24, "record staging fits the table");
+    if ((int)threadIdx.x < nrec) {
+      const int m = ffirst + f0 + threadIdx.x;
+      const int src = fsrc[(long long)b * cap_feat + m];
+      const int i = src >> 2, k = src & 3;
+      const FRec rec = recs[(long long)b * cap_list + i];
+      const int li = list[(long long)b * cap_list + i].level_index;
+      const float kw = dp.multi ? (float)((2.0 * kPI / 255.0) * (double)((rec.w >> (8 * k)) & 0xFFu))
+                                : __uint_as_float(rec.w);
+      const float kx = (float)(rec.x & 0x00FFFFFFu) / 1024.0f;
+      const float ky = (float)(rec.y & 0x00FFFFFFu) / 1024.0f;
+      const float kz = (float)(rec.z & 0x0000FFFFu) / 256.0f;
+      const float oss = dp.octave_sigma * (float)(1 << (li / dp.dog));
+      const float offset = dp.lowe_origin ? 0.0f : 0.5f;
+      HostKeypoint hk;
+      hk.x = __fadd_rn(__fmul_rn(oss, kx - 0.5f), offset);
+      hk.y = __fadd_rn(__fmul_rn(oss, ky - 0.5f), offset);
+      hk.s = oss * kz;
+      hk.o = (float)fmod(2.0 * kPI - (double)kw, 2.0 * kPI);
+      hk.response = dm_h2f(((rec.x & 0xFF000000u) >> 16) | ((rec.y & 0xFF000000u) >> 24));
+      hk.level = (uint16_t)li;
+      hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
+      *reinterpret_cast<HostKeypoint*>(kst + 6 * threadIdx.x) = hk;
+    }
+    __syncthreads();
+    const uint2* const k2 = reinterpret_cast<const uint2*>(kst);
+    uint2* const out = reinterpret_cast<uint2*>(keys + obase + f0);
+    uint2* const hout = dp.hkeys ? reinterpret_cast<uint2*>(dp.hkeys + obase + f0) : nullptr;
+    for (int j = threadIdx.x; j < 3 * nrec; j += 256) {
+      const uint2 v = k2[j];
+      out[j] = v;
+      if (hout) hout[j] = v;
+    }
+    __syncthreads();
+  }
+  if (!desc) return;
   for (int i = lane; i < DC_ROWS; i += 64) rows[i] = 0.0f;
   float* const mycol = rows + mycell * 4 + sub;  // + DC_BIN_PITCH*bin: the column this lane fills (cell, slot `sub`)
   const float* const rdbin = rows + sub * DC_BIN_PITCH + mycell * 4;  // + 4*DC_BIN_PITCH*k: bins sub, sub+4, sub+8
@@ -424,21 +468,6 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     const float ky = (float)(rec.y & 0x00FFFFFFu) / 1024.0f;
     const float kz = (float)(rec.z & 0x0000FFFFu) / 256.0f;
 
-    if (lane == 0) {  // host keypoint record, PyramidCU.cpp:866-906 / :1097-1137 (host arithmetic)
-      const float oss = dp.octave_sigma * (float)(1 << (li / dp.dog));
-      const float offset = dp.lowe_origin ? 0.0f : 0.5f;
-      HostKeypoint hk;
-      hk.x = __fadd_rn(__fmul_rn(oss, kx - 0.5f), offset);
-      hk.y = __fadd_rn(__fmul_rn(oss, ky - 0.5f), offset);
-      hk.s = oss * kz;
-      hk.o = (float)fmod(2.0 * kPI - (double)kw, 2.0 * kPI);
-      hk.response = dm_h2f(((rec.x & 0xFF000000u) >> 16) | ((rec.y & 0xFF000000u) >> 24));
-      hk.level = (uint16_t)li;
-      hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
-      keys[obase + oidx] = hk;
-      if (dp.hkeys) dp.hkeys[obase + oidx] = hk;
-    }
-    if (!desc) continue;
 
     const float spt = fabsf(kz * dp.window_factor);
     float s, c;

@@ -1,41 +1,55 @@
 #!/usr/bin/env python3
-"""Busy fraction and overlap of the kernels in a rocprofv3 kernel trace (several streams):
-   python tools/trace_overlap.py <dir with *_kernel_trace.csv> [skip_fraction]"""
+"""Concurrency summary of a rocprofv3 --kernel-trace CSV of a pipelined bench run:
+
+  python tools/trace_overlap.py <dir with *_kernel_trace.csv> [skip_fraction]
+
+Over the steady part of the trace (the first `skip_fraction`, default 0.3, of the dispatches is dropped): wall time,
+time with at least one kernel running, mean number of kernels in flight, and per kernel the summed duration next to
+its share of the wall time -- set against a single-stream trace this shows which kernels stretch when they overlap.
+"""
+import collections
 import csv
 import glob
+import re
 import sys
 
 
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("hess::", "")
+    return re.sub(r"\(.*", "", name)
+
+
 def main():
-    f = glob.glob(f"{sys.argv[1]}/**/*kernel_trace.csv", recursive=True)[0]
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-    iv = []
-    for r in csv.DictReader(open(f)):
-        iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
-    iv.sort()
-    t0, t1 = iv[0][0], max(e for _, e, _ in iv)
-    lo = t0 + (t1 - t0) * skip  # steady state: skip warm-up
+    d = sys.argv[1]
+    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+    rows = []
+    for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+    rows.sort()
+    rows = rows[int(len(rows) * skip):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
     ev = []
-    tot = 0
-    for s, e, _ in iv:
-        if e <= lo:
-            continue
-        s = max(s, lo)
-        ev.append((s, 1)); ev.append((e, -1)); tot += e - s
+    for s, e, _ in rows:
+        ev.append((s, 1)); ev.append((e, -1))
     ev.sort()
-    busy, depth, last = 0, 0, None
-    hist = {}
-    for t, d in ev:
-        if last is not None and depth > 0:
+    busy = 0; depth = 0; last = t0; area = 0
+    hist = collections.Counter()
+    for t, k in ev:
+        if depth > 0:
             busy += t - last
-        if last is not None:
-            hist[depth] = hist.get(depth, 0) + (t - last)
-        depth += d
-        last = t
-    span = t1 - lo
-    print(f"span {span/1e6:.2f} ms, union busy {busy/span:.3f}, sum of kernel time / span {tot/span:.3f}")
-    for k in sorted(hist):
-        print(f"  {k} kernels in flight: {hist[k]/span:.3f}")
+        area += depth * (t - last)
+        hist[depth] += t - last
+        depth += k; last = t
+    wall = t1 - t0
+    print(f"dispatches {len(rows)}  wall {wall/1e6:.3f} ms  busy(>=1 kernel) {busy/1e6:.3f} ms ({busy/wall:.3f})  mean kernels in flight {area/wall:.2f}")
+    print("time share by kernels in flight:", {k: round(v / wall, 3) for k, v in sorted(hist.items())})
+    per = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in rows:
+        per[n][0] += e - s; per[n][1] += 1
+    print("kernel,calls,sum_ms,avg_us,sum/wall")
+    for n, (tot, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        print(f"{n},{c},{tot/1e6:.3f},{tot/c/1e3:.2f},{tot/wall:.3f}")
 
 
 if __name__ == "__main__":
