@@ -173,7 +173,8 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
                        const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
                        float* desc, int cap_feat, int batch);
 // Exclusive prefix of the per-image feature totals: img_base[0..batch] (packed output layout).
-void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch);
+void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch, const int* overflow,
+                       int* host_small);
 
 // Device evaluation of the elementary functions for the parity tests.
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);

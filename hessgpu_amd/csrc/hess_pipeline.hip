@@ -77,8 +77,13 @@ struct hess_ctx {
   bool use_topk = false, multi = false;
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
-  DevBuf gauss, deth, got, input_f32, upsampled, stage, rowmask, rowcnt, rowoff, level_count, raw_total, overflow, raw, sel,
-      hist, sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
+  DevBuf gauss, deth, got, input_f32, upsampled, stage, rowoff, level_count, raw_total, raw, sel,
+      sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
+  // Everything the detection stages expect zeroed lives in one allocation and is cleared by one fill per batch:
+  // overflow flags, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
+  DevBuf zeroed;
+  size_t zeroed_used = 0;
+  struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist;
   // host results
   int batch = 0;
   std::vector<int> counts;
@@ -330,8 +335,15 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->got, (size_t)gt * 8))) return rc;
   if ((rc = ensure(c, c->input_f32, (size_t)B * ws * hs * 4))) return rc;
   if (ds < 0 && (rc = ensure(c, c->upsampled, (size_t)B * ws * hs * 4))) return rc;
-  if ((rc = ensure(c, c->rowmask, (size_t)B * g.NM * 8))) return rc;
-  if ((rc = ensure(c, c->rowcnt, (size_t)B * g.NR * 4))) return rc;
+  {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_cnt = 256, o_hist = o_cnt + up((size_t)B * g.NR * 4);
+    const size_t o_mask = o_hist + (c->use_topk ? up((size_t)B * kHistBins * 4) : 0);
+    c->zeroed_used = o_mask + up((size_t)B * g.NM * 8);
+    if ((rc = ensure(c, c->zeroed, c->zeroed_used))) return rc;
+    char* z = (char*)c->zeroed.p;
+    c->overflow.p = z; c->rowcnt.p = z + o_cnt; c->hist.p = z + o_hist; c->rowmask.p = z + o_mask;
+  }
   if ((rc = ensure(c, c->rowoff, (size_t)B * g.NR * 4))) return rc;
   if ((rc = ensure(c, c->level_count, (size_t)B * g.nlev * 4))) return rc;
   if ((rc = ensure(c, c->sel_level_count, (size_t)B * g.nlev * 4))) return rc;
@@ -340,11 +352,9 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->feat_total, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->feat_first, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->img_base, (size_t)(B + 1) * 4))) return rc;
-  if ((rc = ensure(c, c->overflow, 16))) return rc;
   if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
   if (c->use_topk) {
     if ((rc = ensure(c, c->sel, (size_t)B * cap_sel * sizeof(RawKey)))) return rc;
-    if ((rc = ensure(c, c->hist, (size_t)B * kHistBins * 4))) return rc;
   }
   if ((rc = ensure(c, c->recs, (size_t)B * cap_sel * sizeof(FRec)))) return rc;
   if ((rc = ensure(c, c->ocount, (size_t)B * cap_sel * 4))) return rc;
@@ -505,7 +515,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   LimitParams lp;
   lp.method = p.truncate_method;
   lp.threshold = p.feature_count_threshold;
-  HIP_TRY(c, hipMemsetAsync(c->overflow.p, 0, 16, st));
+  HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, c->zeroed_used, st));  // overflow flags, row counts, histogram, masks
   {
     // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
     double det_bytes = 0;
@@ -558,7 +568,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
                       (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p + 1, batch);
-  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, batch);
+  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, batch, (const int*)c->overflow.p,
+                    c->host_direct ? (int*)c->h_small.p : nullptr);
   (void)hipEventRecord(c->ev[6], st);
   // ---- descriptors (GetFeatureDescriptors) ----
   DescParams dsp;
@@ -677,7 +688,8 @@ int enqueue_user(hess_ctx* c) {
   launch_feature_scan(st, g, lp, 0, list, list_total, c->cap_raw, (const int*)c->ocount.p, (int*)c->foffset.p,
                       (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p + 1, 1);
-  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, 1);
+  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, 1, (const int*)c->overflow.p,
+                    c->host_direct ? (int*)c->h_small.p : nullptr);
   (void)hipEventRecord(c->ev[6], st);
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
@@ -710,8 +722,10 @@ int submit_impl(hess_ctx* c, const PendingRun& r) {
   rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
   if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(hs, c->img_base.p, (size_t)(r.batch + 1) * 4, hipMemcpyDeviceToHost, c->st));
-  HIP_TRY(c, hipMemcpyAsync(hs + r.batch + 1, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+  if (!c->host_direct) {  // (with host-direct delivery image_base_kernel has stored both into h_small itself)
+    HIP_TRY(c, hipMemcpyAsync(hs, c->img_base.p, (size_t)(r.batch + 1) * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(hs + r.batch + 1, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+  }
   return 0;
 }
 
@@ -843,8 +857,8 @@ void hess_destroy(hess_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
-  DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->rowmask, &c->rowcnt, &c->rowoff,
-                    &c->level_count, &c->raw_total, &c->overflow, &c->raw, &c->sel, &c->hist, &c->sel_total,
+  DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
+                    &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
                     &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
   for (DevBuf* b : bufs) release(*b);

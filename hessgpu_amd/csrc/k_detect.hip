@@ -891,10 +891,9 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                          const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
   (void)gauss;
-  (void)hipMemsetAsync(rowcnt, 0, (size_t)batch * g.NR * sizeof(int), st);
+  // rowcnt and rowmask arrive zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
   // streaming scan (sets mask bits with atomics); its candidate queue packs row and column in 14 bits each
   if (g.dog <= 5 && g.o[0].wa < (1 << 14) && g.o[0].h < (1 << 14)) {
-    (void)hipMemsetAsync(rowmask, 0, (size_t)batch * g.NM * sizeof(uint64_t), st);
     unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);
     const dim3 grid(g.nstream, batch), blk(256);
     switch (g.dog) {
@@ -933,8 +932,7 @@ void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& d
 
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
                  unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch) {
-  // a failure here is picked up with the launches' by the hipGetLastError() that follows the enqueue (submit_impl)
-  (void)hipMemsetAsync(hist, 0, (size_t)batch * kHistBins * sizeof(unsigned), st);
+  // hist arrives zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
   hipLaunchKernelGGL(topk_hist_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, K, raw, raw_total,
                      cap_raw, hist);
   hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist, sel,

@@ -651,18 +651,29 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   }
 }
 
-__global__ void image_base_kernel(const int* feat_total, int* img_base, int batch) {
+// Packed output offsets of the batch; with host-direct delivery the offsets and the four overflow words also go to
+// the pinned host block the caller reads after the stream has drained (no device->host copy commands).
+__global__ void image_base_kernel(const int* feat_total, int* img_base, int batch, const int* overflow, int* host_small) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
-    for (int b = 0; b < batch; b++) { img_base[b] = acc; acc += feat_total[b]; }
+    for (int b = 0; b < batch; b++) {
+      img_base[b] = acc;
+      if (host_small) host_small[b] = acc;
+      acc += feat_total[b];
+    }
     img_base[batch] = acc;
+    if (host_small) {
+      host_small[batch] = acc;
+      for (int i = 0; i < 4; i++) host_small[batch + 1 + i] = overflow[i];
+    }
   }
 }
 
 }  // namespace
 
-void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch) {
-  hipLaunchKernelGGL(image_base_kernel, dim3(1), dim3(64), 0, st, feat_total, img_base, batch);
+void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch, const int* overflow,
+                       int* host_small) {
+  hipLaunchKernelGGL(image_base_kernel, dim3(1), dim3(64), 0, st, feat_total, img_base, batch, overflow, host_small);
 }
 
 void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,
