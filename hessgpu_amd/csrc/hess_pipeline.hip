@@ -500,9 +500,14 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   }
   (void)hipEventRecord(c->ev[1], st);
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
-  for (int o = 0; o < g.noct; o++) {  // the octave's top level has no successor blur: standalone kernel
-    ProfScope ps(c, HESS_K_HESSIAN, (double)batch * g.o[o].plane * 8.0);
-    launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
+  {  // the octaves' top levels have no successor blur: one standalone launch for all of them
+    double px = 0;
+    for (int o = 0; o < g.noct; o++) px += g.o[o].plane;
+    ProfScope ps(c, HESS_K_HESSIAN, (double)batch * px * 8.0);
+    if (s.level_max >= 1 && s.level_max <= g.dog)  // (never with the reference's level layout: level_max = dog + 1)
+      for (int o = 0; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
+    else
+      launch_hessian_level(st, g, gauss, deth, s.level_max, s.norm[s.level_max], batch);
   }
   }  // !(user_mode && on_current)
   if (user_mode) return enqueue_user(c);

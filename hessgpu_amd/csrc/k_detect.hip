@@ -129,31 +129,38 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
 // 3 (the one-row kernel above measured 2x its algorithmic bytes at HBM: the three readers of a row land
 // on different XCDs).  Same 1-D neighbour semantics: the columns left/right of the group come from the
 // adjacent lanes, and from explicit 1-D-indexed loads at row ends and wavefront edges.
-__global__ __launch_bounds__(256) void hessian_rows4_kernel(HessArgs a) {
-  const int groups_per_row = a.wa >> 2;
-  const int bands = (a.h + 3) >> 2;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+// det-H of one level of every octave in a single launch (the octaves' top levels: nobody's source level, so no
+// Gaussian launch computes it on the side).  1 thread = 4 px x 4 rows; neighbour columns from the adjacent lanes.
+__global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm) {
+  int blk = blockIdx.x, o = 0;  // block -> octave: octaves back to back, whole blocks each (uniform scalar walk)
+  for (; o < g.noct - 1; o++) {
+    const int nb = ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
+    if (blk < nb) break;
+    blk -= nb;
+  }
+  const int wa = g.o[o].wa, h = g.o[o].h, n = g.o[o].plane;
+  const int groups_per_row = wa >> 2;
+  const int bands = (h + 3) >> 2;
+  const int gid = blk * 256 + threadIdx.x;
   if (gid >= groups_per_row * bands) return;
-  int band = (int)(((float)gid + 0.5f) * a.inv_groups);
+  int band = (int)(((float)gid + 0.5f) * (1.0f / (float)groups_per_row));
   int rem = gid - band * groups_per_row;
   if (rem < 0) { band--; rem += groups_per_row; }
   else if (rem >= groups_per_row) { band++; rem -= groups_per_row; }
   const int x = rem << 2, r0 = band << 2;
-  const int z = blockIdx.y;
-  const int l = a.level_first + z / a.batch, b = z % a.batch;
-  const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
-  const float* src = a.gauss + poff;
-  const int n = a.plane;
+  const int b = blockIdx.y;
+  const long long poff = g.o[o].lvl_off + ((long long)level * g.B + b) * n;
+  const float* src = gauss + poff;
   const int lane = threadIdx.x & 63;
   const bool edge_l = (x == 0) || (lane == 0);
-  const bool edge_r = (x + 4 == a.wa) || (lane == 63) || (gid == groups_per_row * bands - 1);
+  const bool edge_r = (x + 4 == wa) || (lane == 63) || (gid == groups_per_row * bands - 1);
 
   float R[6][6];  // rows r0-1 .. r0+4, columns x-1 .. x+4
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const int row = r0 - 1 + k;
-    const bool in = row >= 0 && row < a.h;
-    const float4 q = *reinterpret_cast<const float4*>(src + (in ? row : 0) * a.wa + x);
+    const bool in = row >= 0 && row < h;
+    const float4 q = *reinterpret_cast<const float4*>(src + (in ? row : 0) * wa + x);
     R[k][1] = in ? q.x : 0.0f; R[k][2] = in ? q.y : 0.0f; R[k][3] = in ? q.z : 0.0f; R[k][4] = in ? q.w : 0.0f;
   }
 #pragma unroll
@@ -163,17 +170,16 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(HessArgs a) {
   }
   if (edge_l) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) R[k][0] = tex1(src, n, (r0 - 1 + k) * a.wa + x - 1);
+    for (int k = 0; k < 6; k++) R[k][0] = tex1(src, n, (r0 - 1 + k) * wa + x - 1);
   }
   if (edge_r) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) R[k][5] = tex1(src, n, (r0 - 1 + k) * a.wa + x + 4);
+    for (int k = 0; k < 6; k++) R[k][5] = tex1(src, n, (r0 - 1 + k) * wa + x + 4);
   }
-  const float norm = a.norm[l];
 #pragma unroll
   for (int k = 1; k <= 4; k++) {
     const int row = r0 + k - 1;
-    if (row >= a.h) break;
+    if (row >= h) break;
     float hv[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(HessArgs a) {
       const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;       // :538
       hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;             // :553
     }
-    *reinterpret_cast<float4*>(a.deth + poff + row * a.wa + x) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    *reinterpret_cast<float4*>(deth + poff + row * wa + x) = make_float4(hv[0], hv[1], hv[2], hv[3]);
   }
 }
 
@@ -876,16 +882,16 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
   a.batch = batch; a.lvl_off = og.lvl_off; a.got_off = og.got_off;
   a.inv_groups = 1.0f / (float)(og.wa >> 2);
   for (int l = 0; l < g.dog + 2; l++) a.norm[l] = norms[l];
-  const bool any_got = level_first <= g.dog && level_last >= 1;
-  if (!any_got) {  // det-H only: the four-row kernel
-    const int groups = (og.wa >> 2) * ((og.h + 3) >> 2);
-    hipLaunchKernelGGL(hessian_rows4_kernel, dim3((groups + 255) / 256, (level_last - level_first + 1) * batch),
-                       dim3(256), 0, st, a);
-    return;
-  }
   const int groups = (og.wa >> 2) * og.h;
   hipLaunchKernelGGL(hessian_kernel, dim3((groups + 255) / 256, (level_last - level_first + 1) * batch), dim3(256),
                      0, st, a);
+}
+
+void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
+                          int batch) {
+  int blocks = 0;
+  for (int o = 0; o < g.noct; o++) blocks += ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
+  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm);
 }
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
