@@ -115,7 +115,8 @@ struct DescParams {
 // from the window it has staged anyway (ComputeHessian_Kernel, ProgramCU.cu:523-595).
 void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
                   long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
-                  float* deth_src = nullptr, float* got_src = nullptr, float norm_src = 0.0f);
+                  float* deth_src = nullptr, float* got_src = nullptr, float norm_src = 0.0f,
+                  float* decim_dst = nullptr, int decim_w = 0, int decim_h = 0);
 
 // Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,

@@ -469,6 +469,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       src_f = (const float*)c->upsampled.p;
     }
   }
+  // The launch that produces the down-sampling level also writes level 0 of the next octave (its even rows and
+  // columns): no decimation launches.  (A down-sampling level 0 is nobody's product: separate kernel then.)
+  const bool fused_decim = s.level_ds >= 1 && s.level_ds <= s.level_max;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
     // image b of level l lives at plane_ptr(.., o, l) + b*plane: a batch is contiguous per level
@@ -483,7 +486,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       } else {
         (void)hipMemcpyAsync(plane_ptr(gauss, 0, 0), src_f, (size_t)batch * og.plane * 4, hipMemcpyDeviceToDevice, st);
       }
-    } else {
+    } else if (!fused_decim) {
       ProfScope ps(c, HESS_K_DOWNSAMPLE, (double)batch * og.plane * 8.0);
       launch_downsample(st, plane_ptr(gauss, o - 1, s.level_ds), g.o[o - 1].wa, g.o[o - 1].plane,
                         plane_ptr(gauss, o, 0), og.wa, og.h, batch);
@@ -492,10 +495,13 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       // level l from level l-1; the same launch emits det-H (+ gradient/theta) of level l-1 from the
       // source window it stages: 8 B R+W for the blur, 4 B (+8 B) W for the fused planes
       const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
-      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)));
+      const bool decim = fused_decim && l == s.level_ds && o + 1 < g.noct;
+      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)) +
+                                        (decim ? (double)batch * g.o[o + 1].plane * 4.0 : 0.0));
       launch_gauss(st, plane_ptr(gauss, o, l - 1), nullptr, og.wa, og.plane, plane_ptr(gauss, o, l), og.wa, og.h,
                    batch, s.taps[l], plane_ptr(deth, o, l - 1),
-                   src_got ? got + 2 * (og.got_off + (long long)(l - 2) * g.B * og.plane) : nullptr, s.norm[l - 1]);
+                   src_got ? got + 2 * (og.got_off + (long long)(l - 2) * g.B * og.plane) : nullptr, s.norm[l - 1],
+                   decim ? plane_ptr(gauss, o + 1, 0) : nullptr, decim ? g.o[o + 1].wa : 0, decim ? g.o[o + 1].h : 0);
     }
   }
   (void)hipEventRecord(c->ev[1], st);

@@ -37,6 +37,10 @@ struct GaussArgs {
   float* deth_src;
   float2* got_src;   // may be null (levels 0 and dog+1 have no gradient plane)
   float norm_src;    // sigma^4 of the source level
+  // level 0 of the next octave = the produced level point-sampled at the even rows and columns (DownsampleKernel,
+  // ProgramCU.cu:312-326: dst(x, y) = src(min(2x, w-1), 2y)); null unless this launch produces the down-sampling level
+  float* decim_dst;  // [batch][dh][dw]
+  int dw, dh;
   Taps taps;
 };
 
@@ -265,6 +269,19 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
         int y = y0 + rg * 4 + j;
         if (y < h) *reinterpret_cast<float2*>(&d[(long long)y * w + x]) = acc[j];
       }
+      if (a.decim_dst) {  // block-uniform.  x and y0 + 4*rg are even: rows j = 0, 2 and column .x are the sampled ones
+        float* dd = a.decim_dst + img * (long long)a.dw * a.dh;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const int y = y0 + rg * 4 + j;
+          if (y < h && (y >> 1) < a.dh) {
+            float* row = dd + (long long)(y >> 1) * a.dw;
+            if ((x >> 1) < a.dw) row[x >> 1] = acc[j].x;  // (the next octave may be narrower than w/2: widths halve unaligned)
+            // columns of the next octave beyond w/2 (its width is aligned up to 4) repeat the source's last column
+            if (x == w - 2) for (int xx = w >> 1; xx < a.dw; xx++) row[xx] = acc[j].y;
+          }
+        }
+      }
     }
   }
 }
@@ -378,8 +395,9 @@ __global__ __launch_bounds__(256) void downsample_kernel(const float* src, int s
 
 void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
                   long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
-                  float* deth_src, float* got_src, float norm_src) {
+                  float* deth_src, float* got_src, float norm_src, float* decim_dst, int decim_w, int decim_h) {
   GaussArgs a;
+  a.decim_dst = decim_dst; a.dw = decim_w; a.dh = decim_h;
   a.src = src; a.src_u8 = src_u8; a.src_pitch = src_pitch; a.src_img_stride = src_img_stride;
   a.dst = dst; a.w = wa; a.h = h; a.taps = taps;
   a.deth_src = deth_src; a.got_src = reinterpret_cast<float2*>(got_src); a.norm_src = norm_src;

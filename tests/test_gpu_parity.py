@@ -222,10 +222,13 @@ def test_parity_input_formats(gpu_ctx_factory, dtype, fmt):
     _assert_same_features(gk, gd, ok, od, dtype)
 
 
-@pytest.mark.parametrize("w,h", [(251, 50), (124, 24), (125, 25), (372, 73), (1000, 97)])
+@pytest.mark.parametrize("w,h", [(251, 50), (124, 24), (125, 25), (372, 73), (1000, 97), (324, 223), (652, 210)])
 def test_parity_noise_ragged(gpu_ctx_factory, w, h):
     """Dense extrema on sizes that straddle the extrema scan's strip (124 columns) and segment
-    (24 rows) boundaries; a low threshold keeps the candidate queues of the scan full."""
+    (24 rows) boundaries; a low threshold keeps the candidate queues of the scan full.  The last two sizes walk the
+    octave widths 324, 164, 84, 40 and 652, 328, 164, 84: a next octave wider than half of the previous one (width
+    aligned up: its last columns repeat the source's last column) and one narrower (84 -> 40: widths halve
+    unaligned), the two cases of the decimation fused into the Gaussian launch."""
     rng = np.random.RandomState(w * 131 + h)
     img = (rng.rand(2, h, w) * 255).astype(np.uint8)
     kw = dict(dog_threshold=0.0005, edge_threshold=50.0)
