@@ -321,7 +321,7 @@ def rooflines(prof, steps, timed_keys, images, prof_dev=None):
         achieved = fbytes / dur / 1e9
         e = {
             "bound": "hbm",
-            "kernel": "descriptor_kernel (one wavefront per feature: rotated-grid histogram + normalisation + result stores)",
+            "kernel": "descriptor_kernel<true> (one wavefront per feature: rotated-grid histogram + normalisation + result stores incl. the pinned host mirror)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profile_value("descriptor_counters.json", "hbm_bytes_per_launch"),
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1),
@@ -338,6 +338,7 @@ def rooflines(prof, steps, timed_keys, images, prof_dev=None):
             ddur = dd["ms"] * 1e-3 / dd["launches"]
             e["without_host_mirror"] = {
                 "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(fbytes / ddur / 1e9, 1), "unit": "GB/s",
+                "kernel": "descriptor_kernel<false>",
                 "note": "same launch on a context that delivers results by a copy after the kernels (HESS_HOST_DIRECT=0): "
                         "the shipped launch also stores keypoints + descriptors into pinned host memory and, alone "
                         "on the device, waits for PCIe",

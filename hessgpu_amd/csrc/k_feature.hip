@@ -371,6 +371,10 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
 // The kernel is bound by vector issue, not by latency: builds with 2, 3 and 4 wavefronts per SIMD run alike, builds
 // with 5, 6 or 8 (fewer registers, or smaller unroll) measured 5-30 % slower (profiles/README.md, round 2), so the
 // register count must not decide it.
+// HOST_MIRROR: the packed results are also stored into their pinned host mirrors (dp.hkeys / dp.hdesc); a template
+// parameter so that the two forms carry different names in profiles (alone on the device the mirroring form waits
+// for PCIe).
+template <bool HOST_MIRROR>
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
                                                          int cap_list, const FRec* recs,
                                                          const int* fsrc, const int* feat_total,
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     __syncthreads();
     const uint2* const k2 = reinterpret_cast<const uint2*>(kst);
     uint2* const out = reinterpret_cast<uint2*>(keys + obase + f0);
-    uint2* const hout = dp.hkeys ? reinterpret_cast<uint2*>(dp.hkeys + obase + f0) : nullptr;
+    uint2* const hout = (HOST_MIRROR && dp.hkeys) ? reinterpret_cast<uint2*>(dp.hkeys + obase + f0) : nullptr;
     for (int j = threadIdx.x; j < 3 * nrec; j += 256) {
       const uint2 v = k2[j];
       out[j] = v;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         }
       }
       if (lane < 32) *reinterpret_cast<float2*>(dout + lane * 2) = v;
-      if (dp.hdesc && lane < 32) *reinterpret_cast<float2*>(dp.hdesc + (obase + oidx) * dim + lane * 2) = v;
+      if (HOST_MIRROR && dp.hdesc && lane < 32) *reinterpret_cast<float2*>(dp.hdesc + (obase + oidx) * dim + lane * 2) = v;
     } else {
       float4 v = make_float4(0, 0, 0, 0);
       if (lane < 32) v = *reinterpret_cast<const float4*>(&dl[wv][lane * 4]);
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         }
       }
       if (lane < 32) *reinterpret_cast<float4*>(dout + lane * 4) = v;
-      if (dp.hdesc && lane < 32) *reinterpret_cast<float4*>(dp.hdesc + (obase + oidx) * dim + lane * 4) = v;
+      if (HOST_MIRROR && dp.hdesc && lane < 32) *reinterpret_cast<float4*>(dp.hdesc + (obase + oidx) * dim + lane * 4) = v;
     }
   }
 }
@@ -700,8 +704,12 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   int blocks = (cap_feat + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(descriptor_kernel, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
-                     feat_total, feat_first, img_base, got, keys, desc, cap_feat);
+  if (dp.hkeys || dp.hdesc)
+    hipLaunchKernelGGL(descriptor_kernel<true>, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
+                       feat_total, feat_first, img_base, got, keys, desc, cap_feat);
+  else
+    hipLaunchKernelGGL(descriptor_kernel<false>, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
+                       feat_total, feat_first, img_base, got, keys, desc, cap_feat);
 }
 
 }  // namespace hess

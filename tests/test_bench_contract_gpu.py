@@ -29,7 +29,9 @@ def test_bench_json_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
     kernels = {rf["kernel"].split()[0], d["roofline_secondary"]["kernel"].split()[0]}
-    assert kernels == {"gauss_kernel", "descriptor_kernel"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
+    assert kernels == {"gauss_kernel", "descriptor_kernel<true>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
+    dk = rf if rf["kernel"].startswith("descriptor") else d["roofline_secondary"]
+    assert dk["without_host_mirror"]["kernel"] == "descriptor_kernel<false>" and dk["without_host_mirror"]["avg_launch_us"] > 0
     assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
     assert 0 < d["value_host_to_host"] and 0 < d["latency_ms_single_image"] < 100
     assert d["config"]["distinct_images_per_gpu"] == 2 and "configs[1]" in d["config"]["workload"]

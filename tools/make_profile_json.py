@@ -29,11 +29,12 @@ def main():
     gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith("gauss_kernel"))
     traffic["valu_insts_per_image"] = round(gv / (3 * batch), 1)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
-    r = rows["descriptor_kernel"]
+    dk = "descriptor_kernel<true>" if "descriptor_kernel<true>" in rows else "descriptor_kernel"  # the form that mirrors to the host
+    r = rows[dk]
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
     feats = dd["features_per_launch"]
     f = lambda k: float(r[k])
-    tr = next((p for p in traffic["per_kernel"] if p["kernel"] == "descriptor_kernel"), None)
+    tr = next((p for p in traffic["per_kernel"] if p["kernel"] == dk), None)
     out = {
         "source": f"profiles/{tag}_counters.csv, {tag}_clock.csv (tools/profile_round.sh {tag}: bench.py --contexts 1, batch {bench['config']['images_per_gpu_per_step']})",
         "features_per_launch": feats,
@@ -44,7 +45,7 @@ def main():
         "wave_time_waiting": round(f("SQ_WAIT_ANY") / f("SQ_WAVE_CYCLES"), 3),
         "wave_time_issue_stalled": round(f("SQ_WAIT_INST_ANY") / f("SQ_WAVE_CYCLES"), 3),
         "wave_time_issuing_valu": round(f("SQ_ACTIVE_INST_VALU") / f("SQ_WAVE_CYCLES"), 3),
-        "effective_clock_ghz": float(clock["descriptor_kernel"]["effective_clock_ghz"]) if "descriptor_kernel" in clock else None,
+        "effective_clock_ghz": float(clock[dk]["effective_clock_ghz"]) if dk in clock else None,
         "hbm_bytes_per_launch": tr["hbm_bytes_per_launch_corrected"] if tr else None,
         "algorithmic_bytes_per_launch": dd["algorithmic_bytes_per_launch"],
     }

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics, single stream (averages comparable with bench.py's hipEvent roofline leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ctx1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg --contexts 1 > $OUT/bench_ctx1.json 2> $OUT/bench_ctx1.err
 # 2. kernel statistics, default pipelined contexts
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg > $OUT/bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg > $OUT/bench_ctx3.json 2> $OUT/bench_ctx3.err
 # 3./4. HBM traffic counters, one pass each
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --contexts 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --contexts 1 > /dev/null 2> $OUT/pmc_write.err
