@@ -152,7 +152,8 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
 // Extrema scan, pass 2: ordered scatter of the detections into the raw list.
 void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                             const float* deth, const uint64_t* rowmask, const int* rowoff,
-                            const int* raw_total, RawKey* raw, int cap_raw, int batch);
+                            const int* raw_total, RawKey* raw, int cap_raw, int batch,
+                            unsigned* hist = nullptr, int topk = 0);  // hist: top-K key histogram, counted on the way
 
 // Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
 // the lower list index, order preserved.  sel may alias nothing; when total < K the list is copied.
@@ -166,10 +167,10 @@ void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, c
                         int* ocount, int batch);
 // Exclusive scan of the per-keypoint orientation counts -> output offsets and feature totals
 // (ReshapeFeatureListCPU, PyramidCU.cpp:720-924; LimitFeatureCount(1)).
-void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi,
-                         const RawKey* list, const int* list_total, int cap_list, const int* ocount,
-                         int* foffset, int* fsrc, int* feat_total, int* feat_first, int cap_feat,
-                         int* overflow, int batch);
+void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi, const RawKey* list,
+                         const int* list_total, int cap_list, const int* ocount, int* foffset, int* fsrc,
+                         int* feat_total, int* feat_first, int cap_feat, int* overflow, int* img_base, int* host_small,
+                         int batch);
 // Descriptor + normalisation + host keypoint record (ComputeDescriptor_Kernel /
 // NormalizeDescriptor_Kernel, ProgramCU.cu:1650-2054; keypoint unpack PyramidCU.cpp:866-906).
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
@@ -177,9 +178,6 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
                        const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
                        float* desc, int cap_feat, int batch);
 // Exclusive prefix of the per-image feature totals: img_base[0..batch] (packed output layout).
-void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch, const int* overflow,
-                       int* host_small);
-
 // Device evaluation of the elementary functions for the parity tests.
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);
 

@@ -540,7 +540,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   {
     ProfScope ps(c, HESS_K_EXTREMA, 0.0);
     launch_extrema_scatter(st, g, dp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowoff.p,
-                           (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch);
+                           (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch,
+                           c->use_topk ? (unsigned*)c->hist.p : nullptr, p.feature_count_threshold);
   }
   (void)hipEventRecord(c->ev[3], st);
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
@@ -578,9 +579,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // ---- multi-orientation expansion (ReshapeFeatureListCPU) ----
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
                       (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
-                      (int*)c->overflow.p + 1, batch);
-  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, batch, (const int*)c->overflow.p,
-                    c->host_direct ? (int*)c->h_small.p : nullptr);
+                      (int*)c->overflow.p, (int*)c->img_base.p, c->host_direct ? (int*)c->h_small.p : nullptr, batch);
   (void)hipEventRecord(c->ev[6], st);
   // ---- descriptors (GetFeatureDescriptors) ----
   DescParams dsp;
@@ -666,7 +665,7 @@ int enqueue_user(hess_ctx* c) {
   }
   int* hs = (int*)c->h_small.p;
   hs[3 * g.B + 4] = n;
-  HIP_TRY(c, hipMemsetAsync(c->overflow.p, 0, 16, st));
+  HIP_TRY(c, hipMemsetAsync(c->overflow.p, 0, 64, st));  // overflow words + feature_scan_kernel's arrival counter
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->raw.p, hl.data(), (size_t)n * sizeof(RawKey), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->recs.p, hr.data(), (size_t)n * sizeof(FRec), hipMemcpyHostToDevice, st));
@@ -698,9 +697,7 @@ int enqueue_user(hess_ctx* c) {
   lp.threshold = -1;  // LimitFeatureCount returns at once for existing keypoints (SiftPyramid.cpp:203)
   launch_feature_scan(st, g, lp, 0, list, list_total, c->cap_raw, (const int*)c->ocount.p, (int*)c->foffset.p,
                       (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
-                      (int*)c->overflow.p + 1, 1);
-  launch_image_base(st, (const int*)c->feat_total.p, (int*)c->img_base.p, 1, (const int*)c->overflow.p,
-                    c->host_direct ? (int*)c->h_small.p : nullptr);
+                      (int*)c->overflow.p, (int*)c->img_base.p, c->host_direct ? (int*)c->h_small.p : nullptr, 1);
   (void)hipEventRecord(c->ev[6], st);
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
@@ -733,7 +730,7 @@ int submit_impl(hess_ctx* c, const PendingRun& r) {
   rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
   if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
-  if (!c->host_direct) {  // (with host-direct delivery image_base_kernel has stored both into h_small itself)
+  if (!c->host_direct) {  // (with host-direct delivery feature_scan_kernel has stored both into h_small itself)
     HIP_TRY(c, hipMemcpyAsync(hs, c->img_base.p, (size_t)(r.batch + 1) * 4, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipMemcpyAsync(hs + r.batch + 1, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
   }

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
 __global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, const float* gauss,
                                                               const float* deth, const uint64_t* rowmask,
                                                               const int* rowoff, const int* raw_total,
-                                                              RawKey* raw, int cap_raw) {
+                                                              RawKey* raw, int cap_raw, unsigned* hist, int topk) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = raw_total[b];
@@ -642,6 +642,10 @@ __global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectPara
   rk.level_index = oct * g.dog + lm1; rk.col = col; rk.row = row; rk.packed = kv.packed;
   rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
   raw[(long long)b * cap_raw + i] = rk;
+  // histogram of the top-K selection key abs(half(response)), 15 bits (topk_select_kernel): counted here, where the
+  // response has just been computed, instead of by a pass of its own over the list.  SelectTopK is skipped when
+  // there are fewer than K detections (PyramidCU.cpp:1886).
+  if (hist && n >= topk) atomicAdd(&hist[(long long)b * kHistBins + ((rk.packed >> 16) & 0x7fffu)], 1u);
 }
 
 // =============================== block scan helpers ==========================================
@@ -701,20 +705,33 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
   __shared__ int lc[kMaxOct * kMaxDog];
   __shared__ int keep[kMaxOct * kMaxDog];
   __shared__ int lds[64];
-  __shared__ int carry;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int* cnt = rowcnt + (long long)b * g.NR;
   int* off = rowoff + (long long)b * g.NR;
   for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
-  if (tid == 0) carry = 0;
   __syncthreads();
-  // level totals
-  for (int i = tid; i < g.NR; i += 1024) {
+  // A thread owns `per` consecutive rows of the list order: level totals first, then (after the -tc rules have
+  // decided which levels stay) one workgroup scan over the threads' sums and a serial walk over the own rows.
+  const int per = (g.NR + 1023) >> 10;
+  const int r0 = tid * per, r1 = min(g.NR, r0 + per);
+  auto level_of_row = [&](int i) {
     int o = 0;
     for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= i) o = k;
-    int li = o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
-    int c = cnt[i];
-    if (c) atomicAdd(&lc[li], c);
+    return o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
+  };
+  {
+    int run_level = -1, run = 0;
+    for (int i = r0; i < r1; i++) {
+      const int c = cnt[i];
+      if (!c) continue;
+      const int li = level_of_row(i);
+      if (li != run_level) {
+        if (run) atomicAdd(&lc[run_level], run);
+        run_level = li; run = 0;
+      }
+      run += c;
+    }
+    if (run) atomicAdd(&lc[run_level], run);
   }
   __syncthreads();
   if (tid == 0) {
@@ -729,39 +746,22 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
     if (total > cap_raw) atomicMax(overflow, total);
   }
   __syncthreads();
-  // ordered exclusive scan of the kept rows
-  for (int base = 0; base < g.NR; base += 1024) {
-    int i = base + tid;
-    int c = 0, kp = 1;
-    if (i < g.NR) {
-      int o = 0;
-      for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= i) o = k;
-      int li = o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
-      kp = keep[li];
-      c = kp ? cnt[i] : 0;
-    }
-    int e, e2, tot, tot2;
-    block_scan2(c, 0, &e, &e2, &tot, &tot2, lds);
-    const int cbase = carry;
-    if (i < g.NR) off[i] = cbase + e;  // dropped rows count 0: offsets stay monotone
-    __syncthreads();
-    if (tid == 0) carry = cbase + tot;
-    __syncthreads();
+  // ordered exclusive scan of the kept rows (dropped rows count 0: offsets stay monotone)
+  int mine = 0;
+  for (int i = r0; i < r1; i++) {
+    const int c = cnt[i];
+    if (c && keep[level_of_row(i)]) mine += c;
+  }
+  int e, e2, tot, tot2;
+  block_scan2(mine, 0, &e, &e2, &tot, &tot2, lds);
+  for (int i = r0; i < r1; i++) {
+    off[i] = e;
+    const int c = cnt[i];
+    if (c && keep[level_of_row(i)]) e += c;
   }
 }
 
 // =============================== top-K =======================================================
-
-__global__ __launch_bounds__(256) void topk_hist_kernel(int K, const RawKey* raw, const int* raw_total, int cap_raw,
-                                                        unsigned* hist) {
-  const int b = blockIdx.y;
-  const int n = raw_total[b];
-  if (n < K) return;  // SelectTopK is skipped when fewer than K detections (PyramidCU.cpp:1886)
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t key = (raw[(long long)b * cap_raw + i].packed >> 16) & 0x7fffu;  // abs(half)
-  atomicAdd(&hist[(long long)b * kHistBins + key], 1u);
-}
 
 __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const RawKey* raw, const int* raw_total,
                                                            int cap_raw, const unsigned* hist, RawKey* sel,
@@ -931,16 +931,14 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
 
 void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                             const float* deth, const uint64_t* rowmask, const int* rowoff, const int* raw_total,
-                            RawKey* raw, int cap_raw, int batch) {
+                            RawKey* raw, int cap_raw, int batch, unsigned* hist, int topk) {
   hipLaunchKernelGGL(extrema_scatter_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, g, dp, gauss, deth,
-                     rowmask, rowoff, raw_total, raw, cap_raw);
+                     rowmask, rowoff, raw_total, raw, cap_raw, hist, topk);
 }
 
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
                  unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch) {
-  // hist arrives zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
-  hipLaunchKernelGGL(topk_hist_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, K, raw, raw_total,
-                     cap_raw, hist);
+  // hist: zeroed by the batch's fill, counted by extrema_scatter_kernel
   hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist, sel,
                      sel_total, sel_level_count, cap_sel);
 }

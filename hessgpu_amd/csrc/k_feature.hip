@@ -245,7 +245,10 @@ __device__ __forceinline__ int block_scan1(int a, int* total, int* lds) {
 __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams lp, int multi, const RawKey* list,
                                                             const int* list_total, int cap_list, const int* ocount,
                                                             int* foffset, int* fsrc, int* feat_total,
-                                                            int* feat_first, int cap_feat, int* overflow) {
+                                                            int* feat_first, int cap_feat, int* overflow,
+                                                            int* img_base, int* host_small) {
+  // overflow: the batch's four overflow words (this kernel raises word 1); word 8 of the same zeroed block counts
+  // the workgroups that have finished, so that the last one can lay out the packed output of the whole batch
   __shared__ int lds[64];
   __shared__ int lc[kMaxOct * kMaxDog];
   __shared__ int carry;
@@ -288,9 +291,28 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
         while (i < g.nlev && (total - lc[i]) > lp.threshold) { total -= lc[i]; first += lc[i]; i++; }
       }
     }
-    if (total > cap_feat) { atomicMax(overflow, total); total = cap_feat; }
+    if (total > cap_feat) { atomicMax(overflow + 1, total); total = cap_feat; }
     feat_total[b] = total;
     feat_first[b] = first;
+    // Packed output offsets of the batch (images back to back), by whichever workgroup finishes last.  With
+    // host-direct delivery the offsets and the overflow words also go to the pinned host block the caller reads once
+    // the stream has drained (no device->host copy commands).
+    __threadfence();
+    if (atomicAdd(overflow + 8, 1) == (int)gridDim.x - 1) {
+      __threadfence();
+      int acc = 0;
+      for (int i = 0; i < (int)gridDim.x; i++) {
+        img_base[i] = acc;
+        if (host_small) host_small[i] = acc;
+        acc += __hip_atomic_load(feat_total + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      img_base[gridDim.x] = acc;
+      if (host_small) {
+        host_small[gridDim.x] = acc;
+        for (int i = 0; i < 4; i++)
+          host_small[gridDim.x + 1 + i] = __hip_atomic_load(overflow + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -655,30 +677,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   }
 }
 
-// Packed output offsets of the batch; with host-direct delivery the offsets and the four overflow words also go to
-// the pinned host block the caller reads after the stream has drained (no device->host copy commands).
-__global__ void image_base_kernel(const int* feat_total, int* img_base, int batch, const int* overflow, int* host_small) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < batch; b++) {
-      img_base[b] = acc;
-      if (host_small) host_small[b] = acc;
-      acc += feat_total[b];
-    }
-    img_base[batch] = acc;
-    if (host_small) {
-      host_small[batch] = acc;
-      for (int i = 0; i < 4; i++) host_small[batch + 1 + i] = overflow[i];
-    }
-  }
-}
-
 }  // namespace
-
-void launch_image_base(hipStream_t st, const int* feat_total, int* img_base, int batch, const int* overflow,
-                       int* host_small) {
-  hipLaunchKernelGGL(image_base_kernel, dim3(1), dim3(64), 0, st, feat_total, img_base, batch, overflow, host_small);
-}
 
 void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,
                         const int* list_total, int cap_list, const float* got, FRec* recs, int* ocount,
@@ -692,9 +691,10 @@ void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, c
 
 void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, int multi, const RawKey* list,
                          const int* list_total, int cap_list, const int* ocount, int* foffset, int* fsrc,
-                         int* feat_total, int* feat_first, int cap_feat, int* overflow, int batch) {
+                         int* feat_total, int* feat_first, int cap_feat, int* overflow, int* img_base, int* host_small,
+                         int batch) {
   hipLaunchKernelGGL(feature_scan_kernel, dim3(batch), dim3(1024), 0, st, g, lp, multi, list, list_total, cap_list,
-                     ocount, foffset, fsrc, feat_total, feat_first, cap_feat, overflow);
+                     ocount, foffset, fsrc, feat_total, feat_first, cap_feat, overflow, img_base, host_small);
 }
 
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
