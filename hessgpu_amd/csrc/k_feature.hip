@@ -13,8 +13,9 @@
 //                compacted in order into an LDS record list; lane j (bin j) reads every record by LDS
 //                broadcast and adds it with coefficient (bin == j ? gradient : 0);
 //   descriptor   lane = cell*4 + q: the four lanes of a cell take four consecutive samples of the cell's
-//                box per iteration, hits are appended in order to the cell's LDS list, and lane (cell, q)
-//                owns bins q, q+4 (q = 0 also 8) of its cell and walks the list (see descriptor_kernel).
+//                box per iteration (the reference's scan order); lane (cell, q) owns bins q, q+4 (q = 0 also 8)
+//                of its cell and adds the iteration's samples to them through a per-wavefront LDS coefficient
+//                table (see descriptor_kernel).
 // Built without the SLP vectoriser (hessgpu_amd/build.py): packed FP32 issues at half rate on gfx950.
 #include <type_traits>
 
@@ -390,9 +391,9 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
 //          non-negative) for the others.  Per bin the additions therefore happen in the reference's order.
 // No sample lists, no compaction: per iteration a lane does two 2-dword LDS stores (set, clear) and three 16-byte loads.
 // Occupancy: four workgroups (= four wavefronts per SIMD) per CU, enforced by the LDS footprint (DC_LDS_PAD_BYTES).
-// The kernel is bound by vector issue, not by latency: builds with 2, 3 and 4 wavefronts per SIMD run alike, builds
-// with 5, 6 or 8 (fewer registers, or smaller unroll) measured 5-30 % slower (profiles/README.md, round 2), so the
-// register count must not decide it.
+// The kernel is bound by vector issue, not by latency: before the all-miss skip, builds with 2, 3 and 4 wavefronts
+// per SIMD ran alike and builds with 5, 6 or 8 (fewer registers, or smaller unroll) 5-30 % slower; with the skip
+// 3, 4, 5 and 6 are within 2 % and 8 is 20 % slower, so the register count must not decide it.
 // HOST_MIRROR: the packed results are also stored into their pinned host mirrors (dp.hkeys / dp.hdesc); a template
 // parameter so that the two forms carry different names in profiles (alone on the device the mirroring form waits
 // for PCIe).
