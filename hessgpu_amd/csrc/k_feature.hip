@@ -44,12 +44,45 @@ __device__ __forceinline__ void level_of(const Geom& g, int li, int* o, int* l) 
 
 // ================================= orientation ===============================================
 
+// e^x for the Gaussian windows of the orientation and descriptor stages: same operations and results as dm_expf() on -87 <= x <= 88 (there
+// its two range clamps select nothing, and p * 2^n by v_ldexp is the same single rounding as the multiplication
+// by the constructed power of two); arguments here lie in [-1.5625, 0] for every sample that is used.
+__device__ __forceinline__ float dm_expf_inrange(float x) {
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float z = r * r;
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, r, 1.3981999507E-3f);
+  p = fmaf(p, r, 8.3334519073E-3f);
+  p = fmaf(p, r, 4.1665795894E-2f);
+  p = fmaf(p, r, 1.6666665459E-1f);
+  p = fmaf(p, r, 5.0000001201E-1f);
+  p = fmaf(p, z, r);
+  p = p + 1.0f;
+  return __builtin_amdgcn_ldexpf(p, (int)n);
+}
+
+
+// Inclusive prefix sum over the 64 lanes by DPP row shifts and row broadcasts (no LDS round trips).
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams op, const RawKey* list,
                                                           const int* list_total, int cap_list, const float* got,
                                                           FRec* recs, int* ocount) {
-  __shared__ __attribute__((aligned(16))) float4 orec[4][64];  // per wavefront: (bin, gradient, weight) records
+  __shared__ __attribute__((aligned(8))) float2 orec[4][66];  // per wavefront: (gradient, weight) records of a step, by bin (+ spare)
   const int lane = threadIdx.x & 63;
-  float4* const myrec = orec[threadIdx.x >> 6];
+  float2* const myrec = orec[threadIdx.x >> 6];
+  __shared__ int osize[4][36];  // per wavefront: samples per bin in the current step
+  int* const mysize = osize[threadIdx.x >> 6];
   const int b = blockIdx.y;
   const int n = list_total[b];
   const int nwaves = gridDim.x * 4;
@@ -111,23 +144,39 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
         const float2 gv = gp[inside ? base + __mul24(iy, width) + ix : 0];  // tex2D point fetch, ProgramCU.cu:1351
         int bin = (int)floorf(gv.y * ten_degree_per_radius);
         bin = (bin < 0) ? bin + 36 : bin;
-        const float e = dm_expf(sq_dist * factor);
-        const uint64_t mk = __builtin_amdgcn_ballot_w64(inside);
-        const int nin = __popcll(mk);
-        if (inside) myrec[__popcll(mk & ((1ull << lane) - 1ull))] = make_float4(__int_as_float(bin), gv.x, e, 0.0f);
-        // lane j adds the records of bin j in list order = the reference's sample order
-        // (ProgramCU.cu:1359: vote[bin] += gradient * weight); for the other bins the coefficient is 0
-        // and fmaf(0, e, vote) == vote (votes and weights are non-negative and finite)
-        for (int k0 = 0; k0 < nin; k0 += 4) {
-          float4 r[4];
+        const float e = dm_expf_inrange(sq_dist * factor);  // in [-2.1, 0] for every sample that is used
+        // The step's samples inside the disc are grouped by bin, each group in lane order = the reference's sample
+        // order (ProgramCU.cu:1359: vote[bin] += gradient * weight): a sample's rank inside its group is the number of
+        // lower lanes with the same bin, lane j (bin j) counts its group; an exclusive scan of the sizes places the groups
+        // back to back in the wavefront's LDS list.  Lane j then reads and adds only its own group -- 8 bytes per
+        // sample and lane instead of a 16-byte broadcast of every sample to all 64 lanes, which kept LDS, not
+        // the vector ALUs, busy.
+        const bool counted = inside & ((unsigned)bin < 36u);  // (a bin outside the histogram has no owner lane)
+        // mask of the lanes whose key equals this lane's key, from the ballots of the six key bits (x == y bit by
+        // bit: and of xnor); lanes without a sample carry key 63, which no bin owner has
+        const int key = counted ? bin : 63;
+        uint32_t same_lo = ~0u, same_hi = ~0u;
 #pragma unroll
-          for (int u = 0; u < 4; u++) r[u] = myrec[min(k0 + u, 63)];  // same address in all lanes: broadcast
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (k0 + u < nin) {  // wavefront-uniform
-              const float cgx = (__float_as_int(r[u].x) == lane) ? r[u].y : 0.0f;
-              vote = fmaf(cgx, r[u].z, vote);
-            }
+        for (int k = 0; k < 6; k++) {
+          const uint64_t bk = __builtin_amdgcn_ballot_w64((key >> k) & 1);
+          const uint32_t km = (uint32_t)-((key >> k) & 1);
+          same_lo &= ~((uint32_t)bk ^ km); same_hi &= ~((uint32_t)(bk >> 32) ^ km);
+        }
+        const int myrank = __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u));
+        // group sizes reach the bin owners through LDS: the last sample of a group knows its size
+        const int gsize = __popc(same_lo) + __popc(same_hi);
+        if (lane < 36) mysize[lane] = 0;
+        if (counted & (myrank + 1 == gsize)) mysize[bin] = gsize;
+        const int mycnt = (lane < 36) ? mysize[lane] : 0;
+        const int mystart = wave_inclusive_scan(mycnt) - mycnt;
+        const int pos = __shfl(mystart, counted ? bin : 0) + myrank;
+        if (counted) myrec[pos] = make_float2(gv.x, e);
+        for (int k = 0; __builtin_amdgcn_ballot_w64(k < mycnt) != 0; k += 2) {
+          if (k < mycnt) {  // two records per trip (a group's records are adjacent; the list has a spare slot)
+            const float2 r0 = myrec[mystart + k], r1 = myrec[mystart + k + 1];  // one ds_read2_b64
+            vote = fmaf(r0.x, r0.y, vote);
+            if (k + 1 < mycnt) vote = fmaf(r1.x, r1.y, vote);
+          }
         }
       }
       // six circular 3-tap box passes (ProgramCU.cu:1364-1379): each pass reads only old values
@@ -333,25 +382,6 @@ constexpr int DC_BIN_PITCH = 80;
 constexpr int DC_ROWS = DC_BINS * DC_BIN_PITCH;
 // dynamic LDS requested at launch on top of the static 17 KB: 36 KB per workgroup -> at most 4 workgroups per CU
 constexpr int DC_LDS_PAD_BYTES = 36 * 1024 - 4 * (4 * DC_ROWS + 4 * 128);
-
-// e^x for the descriptor's Gaussian window: same operations and results as dm_expf() on -87 <= x <= 88 (there
-// its two range clamps select nothing, and p * 2^n by v_ldexp is the same single rounding as the multiplication
-// by the constructed power of two); arguments here lie in [-1.5625, 0] for every sample that is used.
-__device__ __forceinline__ float dm_expf_inrange(float x) {
-  float n = rintf(x * 1.44269504088896341f);
-  float r = fmaf(n, -0.693359375f, x);
-  r = fmaf(n, 2.12194440e-4f, r);
-  float z = r * r;
-  float p = 1.9875691500E-4f;
-  p = fmaf(p, r, 1.3981999507E-3f);
-  p = fmaf(p, r, 8.3334519073E-3f);
-  p = fmaf(p, r, 4.1665795894E-2f);
-  p = fmaf(p, r, 1.6666665459E-1f);
-  p = fmaf(p, r, 5.0000001201E-1f);
-  p = fmaf(p, z, r);
-  p = p + 1.0f;
-  return __builtin_amdgcn_ldexpf(p, (int)n);
-}
 
 typedef const __attribute__((address_space(1))) char* GlobalBytes;  // byte pointer into global memory (HBM)
 typedef float dfloat2 __attribute__((ext_vector_type(2)));
