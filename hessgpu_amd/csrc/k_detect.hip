@@ -608,10 +608,29 @@ __global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectPara
   const int* off = rowoff + (long long)b * g.NR;
   // the detection's row is the LAST row whose exclusive offset is <= i (offsets are non-decreasing;
   // empty rows and rows of levels dropped by -tc count 0 and so never qualify as the last one)
-  int lo = 0, hi = g.NR - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (off[mid] <= i) lo = mid; else hi = mid - 1;
+  // eight-way search: the seven probes of a step are independent loads (one round trip instead of three)
+  int lo = 0, hi = g.NR - 1;  // off[lo] <= i throughout (off[0] = 0); the answer lies in [lo, hi]
+  while (hi - lo >= 8) {
+    const int step = (hi - lo) >> 3;
+    int v[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) v[k] = off[lo + step * (k + 1)];
+    int nl = lo, nh = hi;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const int p = lo + step * (k + 1);
+      if (v[k] <= i) nl = p; else nh = min(nh, p - 1);
+    }
+    lo = nl; hi = nh;
+  }
+  {
+    int v[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) v[k] = off[min(lo + 1 + k, hi)];
+    int r = lo;
+#pragma unroll
+    for (int k = 0; k < 7; k++) if (lo + 1 + k <= hi && v[k] <= i) r = lo + 1 + k;
+    lo = r;
   }
   const int ri = lo;
   int oct = 0;
@@ -622,15 +641,23 @@ __global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectPara
   const uint64_t* mrow = rowmask + (long long)b * g.NM + og.mask_base + (lm1 * og.h + row) * og.w64;
   int rank = i - off[ri];
   int col = -1;
-  for (int wd = 0; wd < og.w64; wd++) {
-    uint64_t m = mrow[wd];
-    const int c = __popcll(m);
-    if (rank < c) {
-      for (int k = 0; k < rank; k++) m &= m - 1;  // drop the lower `rank` set bits
-      col = wd * 64 + __builtin_ctzll(m);
-      break;
+  // the rank-th set bit of the row's mask words, eight words per trip so that their loads are in flight together
+  for (int w0 = 0; w0 < og.w64 && col < 0; w0 += 8) {
+    uint64_t mw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) mw[k] = mrow[min(w0 + k, og.w64 - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (col < 0 && w0 + k < og.w64) {
+        uint64_t m = mw[k];
+        const int c = __popcll(m);
+        if (rank < c) {
+          for (int q = 0; q < rank; q++) m &= m - 1;  // drop the lower `rank` set bits
+          col = (w0 + k) * 64 + __builtin_ctzll(m);
+        }
+        rank -= c;
+      }
     }
-    rank -= c;
   }
   if (col < 0) return;  // cannot happen: counts and masks come from the same pass
   const long long poff = og.lvl_off + ((long long)l * g.B + b) * og.plane;
