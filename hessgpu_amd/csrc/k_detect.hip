@@ -806,72 +806,82 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const 
   if (n >= K) {
     // thread t owns bins [32t, 32t+32); threads are scanned from the high end
     const unsigned* h = hist + (long long)b * kHistBins;
-    int mine = 0;
-    for (int k = 0; k < 32; k++) mine += (int)h[tid * 32 + k];
-    // suffix sum over threads = exclusive prefix over the reversed order
-    int e, e2, tot, tot2;
-    // reverse: thread r = 1023 - tid contributes in scan position tid
-    __shared__ int rev[1024];
-    rev[1023 - tid] = mine;
-    __syncthreads();
-    block_scan2(rev[tid], 0, &e, &e2, &tot, &tot2, lds);
-    // scan position tid corresponds to bins thread (1023 - tid); e = count in strictly higher bins
+    // Thread r = 1023 - tid loads the bins of scan position tid, so that the thread which finds the cut inside its
+    // position walks values it already holds (the walk used to re-read its 32 bins one dependent load at a time).
     const int owner = 1023 - tid;
-    const int above = e, incl = e + rev[tid];
+    int vals[32];
+    {
+      const uint4* hv = reinterpret_cast<const uint4*>(h + owner * 32);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint4 v = hv[q];
+        vals[4 * q] = (int)v.x; vals[4 * q + 1] = (int)v.y; vals[4 * q + 2] = (int)v.z; vals[4 * q + 3] = (int)v.w;
+      }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) mine += vals[k];
+    // suffix sum over the bins = exclusive prefix over the reversed order
+    int e, e2, tot, tot2;
+    block_scan2(mine, 0, &e, &e2, &tot, &tot2, lds);
+    const int above = e, incl = e + mine;  // e = count in strictly higher bins
     if (above < K && incl >= K) {
       int acc = above;
+      bool found = false;
+#pragma unroll
       for (int k = 31; k >= 0; k--) {
-        int c = (int)h[owner * 32 + k];
-        if (acc + c >= K) { s_cut = owner * 32 + k; s_need = K - acc; break; }
+        const int c = vals[k];
+        if (!found && acc + c >= K) { s_cut = owner * 32 + k; s_need = K - acc; found = true; }
         acc += c;
       }
     }
     __syncthreads();
   }
   const int cut = s_cut, need = s_need;
-  // ordered compaction: keep key > cut, and the first `need` entries with key == cut.  A thread takes four
-  // consecutive entries per pass (list order = thread order, then entry order), so a 16 k list needs four passes of
-  // two block scans instead of sixteen.
-  constexpr int IT = 4;
-  for (int base = 0; base < n; base += 1024 * IT) {
-    const int i0 = base + tid * IT;
-    RawKey rk[IT];
-    int keep[IT], tie[IT], nt = 0;
+  // ordered compaction: keep key > cut, and the first `need` entries with key == cut.  A thread takes up to 32
+  // consecutive entries (list order = thread order, then entry order): it classifies them from their keys alone,
+  // one workgroup scan of (ties, sure keeps) gives every thread its tie rank and output position -- of the first T
+  // ties min(T, need) are kept -- and only the kept entries are read in full and written.  A 16 k list is one pass.
+  for (int base = 0; base < n; base += 1024 * 32) {
+    const int left = n - base;
+    const int per = left >= 1024 * 32 ? 32 : (left + 1023) >> 10;  // uniform over the workgroup
+    const int i0 = base + tid * per;
+    uint32_t surem = 0, tiem = 0;
+    for (int j0 = 0; j0 < per; j0 += 8) {  // eight keys per trip: independent loads
+      uint32_t pk[8];
 #pragma unroll
-    for (int j = 0; j < IT; j++) {
-      keep[j] = 0; tie[j] = 0;
-      if (i0 + j < n) {
-        rk[j] = in[i0 + j];
-        if (cut < 0) keep[j] = 1;
-        else {
-          const int key = (int)((rk[j].packed >> 16) & 0x7fffu);
-          if (key > cut) keep[j] = 1;
-          else if (key == cut) tie[j] = 1;
+      for (int u = 0; u < 8; u++) pk[u] = in[min(i0 + j0 + u, n - 1)].packed;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u;
+        if (j < per && i0 + j < n) {
+          const int key = (int)((pk[u] >> 16) & 0x7fffu);
+          if (cut < 0 || key > cut) surem |= 1u << j;
+          else if (key == cut) tiem |= 1u << j;
         }
       }
-      nt += tie[j];
     }
-    int etie, ekeep0, ttie, tkeep0;
-    block_scan2(nt, 0, &etie, &ekeep0, &ttie, &tkeep0, lds);
-    int nk = 0, tseen = s_ties + etie;
-#pragma unroll
-    for (int j = 0; j < IT; j++) {
-      if (tie[j] && tseen < need) keep[j] = 1;
-      tseen += tie[j];
-      nk += keep[j];
-    }
-    int ekeep, edummy, tkeep, tdummy;
-    block_scan2(nk, 0, &ekeep, &edummy, &tkeep, &tdummy, lds);
-    int pos = s_kept + ekeep;
-#pragma unroll
-    for (int j = 0; j < IT; j++)
-      if (keep[j]) {
-        if (pos < cap_sel) out[pos] = rk[j];
-        atomicAdd(&lc[rk[j].level_index], 1);
+    int etie, esure, ttie, tsure;
+    block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
+    const int ties0 = s_ties, kept0 = s_kept;
+    int tseen = ties0 + etie;                                  // ties before this thread's entries
+    int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
+    for (int j = 0; j < per; j++) {
+      const bool tie = (tiem >> j) & 1u;
+      const bool keep = ((surem >> j) & 1u) || (tie && tseen < need);
+      tseen += tie ? 1 : 0;
+      if (keep) {
+        const RawKey rk = in[i0 + j];
+        if (pos < cap_sel) out[pos] = rk;
+        atomicAdd(&lc[rk.level_index], 1);
         pos++;
       }
+    }
     __syncthreads();
-    if (tid == 0) { s_ties += ttie; s_kept += tkeep; }
+    if (tid == 0) {
+      s_ties = ties0 + ttie;
+      s_kept = kept0 + tsure + (min(ties0 + ttie, need) - min(ties0, need));
+    }
     __syncthreads();
   }
   if (tid == 0) sel_total[b] = s_kept < cap_sel ? s_kept : cap_sel;
