@@ -741,10 +741,82 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
   // decided which levels stay) one workgroup scan over the threads' sums and a serial walk over the own rows.
   const int per = (g.NR + 1023) >> 10;
   const int r0 = tid * per, r1 = min(g.NR, r0 + per);
+  // Up to RC rows per thread (images up to ~5000 rows per level) are read once, with independent loads, and kept in
+  // registers; the level of a row follows from walking the level boundaries, not from a division per row.
+  constexpr int RC = 16;
+  __shared__ int oct_h[kMaxOct], oct_base[kMaxOct];
+  for (int i = tid; i < g.noct; i += 1024) { oct_h[i] = g.o[i].h; oct_base[i] = g.o[i].row_base; }
+  __syncthreads();
+  if (per <= RC) {  // uniform
+    int cc[RC];
+#pragma unroll
+    for (int u = 0; u < RC; u++) cc[u] = (u < per && r0 + u < r1) ? cnt[r0 + u] : 0;
+    int o = 0;
+    for (int k = 1; k < g.noct; k++) if (oct_base[k] <= r0) o = k;
+    const int rel = r0 - oct_base[o];
+    const int lm0 = rel / oct_h[o];
+    const int li0 = o * g.dog + lm0, left0 = oct_h[o] - (rel - lm0 * oct_h[o]);  // rows left in the level, this one included
+    int lis[RC];  // level of every own row (levels are consecutive in list order)
+    {
+      int li = li0, lm = lm0, left = left0, oo = o;
+#pragma unroll
+      for (int u = 0; u < RC; u++) {
+        lis[u] = li;
+        if (--left == 0) {
+          li++;
+          if (++lm == g.dog) { lm = 0; oo++; }
+          left = oo < g.noct ? oct_h[oo] : 0x7fffffff;
+        }
+      }
+    }
+    {
+      int run_level = -1, run = 0;
+#pragma unroll
+      for (int u = 0; u < RC; u++) {
+        if (cc[u]) {
+          if (lis[u] != run_level) {
+            if (run) atomicAdd(&lc[run_level], run);
+            run_level = lis[u]; run = 0;
+          }
+          run += cc[u];
+        }
+      }
+      if (run) atomicAdd(&lc[run_level], run);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int before[kMaxOct * kMaxDog];
+      for (int i = 0; i < g.nlev; i++) before[i] = lc[i];
+      int total = apply_level_limits(lc, g.nlev, lp, true);
+      for (int i = 0; i < g.nlev; i++) {
+        keep[i] = (lc[i] == before[i]);  // a level is either kept whole or dropped
+        level_count[b * g.nlev + i] = lc[i];
+      }
+      raw_total[b] = total < cap_raw ? total : cap_raw;
+      if (total > cap_raw) atomicMax(overflow, total);
+    }
+    __syncthreads();
+    // ordered exclusive scan of the kept rows (dropped rows count 0: offsets stay monotone)
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < RC; u++) {
+      cc[u] = (cc[u] && keep[min(lis[u], g.nlev - 1)]) ? cc[u] : 0;
+      mine += cc[u];
+    }
+    int e, e2, tot, tot2;
+    block_scan2(mine, 0, &e, &e2, &tot, &tot2, lds);
+#pragma unroll
+    for (int u = 0; u < RC; u++) {
+      if (u < per && r0 + u < r1) off[r0 + u] = e;
+      e += cc[u];
+    }
+    return;
+  }
+  // more than RC rows per thread: the same steps with the counts re-read from memory
   auto level_of_row = [&](int i) {
     int o = 0;
-    for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= i) o = k;
-    return o * g.dog + (i - g.o[o].row_base) / g.o[o].h;
+    for (int k = 1; k < g.noct; k++) if (oct_base[k] <= i) o = k;
+    return o * g.dog + (i - oct_base[o]) / oct_h[o];
   };
   {
     int run_level = -1, run = 0;
@@ -773,7 +845,6 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
     if (total > cap_raw) atomicMax(overflow, total);
   }
   __syncthreads();
-  // ordered exclusive scan of the kept rows (dropped rows count 0: offsets stay monotone)
   int mine = 0;
   for (int i = r0; i < r1; i++) {
     const int c = cnt[i];
