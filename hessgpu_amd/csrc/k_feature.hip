@@ -307,22 +307,39 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
   for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    int c = 0;
-    if (i < n) {
-      c = multi ? ocount[(long long)b * cap_list + i] : 1;
-      if (c) atomicAdd(&lc[list[(long long)b * cap_list + i].level_index], c);
+  // A thread takes up to 16 consecutive keypoints per pass (their counts and levels read with independent loads),
+  // so a list of 16 k keypoints is one pass with one workgroup scan.
+  constexpr int FC = 16;
+  for (int base = 0; base < n; base += 1024 * FC) {
+    const int left = n - base;
+    const int per = left >= 1024 * FC ? FC : (left + 1023) >> 10;  // uniform over the workgroup
+    const int i0 = base + tid * per;
+    int cc[FC], lv[FC], mine = 0;
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      const bool in = u < per && i0 + u < n;
+      const long long at = (long long)b * cap_list + (in ? i0 + u : 0);
+      cc[u] = in ? (multi ? ocount[at] : 1) : 0;
+      lv[u] = list[at].level_index;
+    }
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      if (cc[u]) atomicAdd(&lc[lv[u]], cc[u]);
+      mine += cc[u];
     }
     int tot;
-    const int e = block_scan1(c, &tot, lds);
+    int e = block_scan1(mine, &tot, lds);
     const int cb = carry;
-    if (i < n) {
-      foffset[(long long)b * cap_list + i] = cb + e;
-      // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
-      // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
-      for (int k = 0; k < c; k++)
-        if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = i * 4 + k;
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      if (u < per && i0 + u < n) {
+        foffset[(long long)b * cap_list + i0 + u] = cb + e;
+        // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
+        // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
+        for (int k = 0; k < cc[u]; k++)
+          if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = (i0 + u) * 4 + k;
+        e += cc[u];
+      }
     }
     __syncthreads();
     if (tid == 0) carry = cb + tot;
