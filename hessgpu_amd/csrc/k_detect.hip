@@ -937,27 +937,23 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const 
     const int ties0 = s_ties, kept0 = s_kept;
     int tseen = ties0 + etie;                                  // ties before this thread's entries
     int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
-    uint32_t keepm = surem;
-    for (uint32_t t = tiem; t && tseen < need; t &= t - 1, tseen++) keepm |= t & (0u - t);  // the first ties, in order
-    while (keepm) {  // four kept entries per trip: independent loads
-      int jj[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        jj[u] = keepm ? __builtin_ctz(keepm) : -1;
-        keepm &= keepm - 1;
-      }
-      RawKey rk[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) rk[u] = in[i0 + max(jj[u], 0)];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (jj[u] >= 0) {
-          if (pos < cap_sel) out[pos] = rk[u];
-          atomicAdd(&lc[rk[u].level_index], 1);
-          pos++;
+    int run_level = -1, run = 0;  // kept entries per level: one LDS atomic per run of equal levels, not per entry
+    for (int j = 0; j < per; j++) {
+      const bool tie = (tiem >> j) & 1u;
+      const bool keep = ((surem >> j) & 1u) || (tie && tseen < need);
+      tseen += tie ? 1 : 0;
+      if (keep) {
+        const RawKey rk = in[i0 + j];
+        if (pos < cap_sel) out[pos] = rk;
+        if (rk.level_index != run_level) {
+          if (run) atomicAdd(&lc[run_level], run);
+          run_level = rk.level_index; run = 0;
         }
+        run++;
+        pos++;
       }
     }
+    if (run) atomicAdd(&lc[run_level], run);
     __syncthreads();
     if (tid == 0) {
       s_ties = ties0 + ttie;
