@@ -956,9 +956,10 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
     // Pageable memory: copied into the pinned staging buffer in chunks, each chunk's transfer enqueued as soon as
     // it is staged, so the copy engine works while the next chunk is being copied.  Large inputs are staged by a
     // few helper threads (one core copies at about 17 GB/s, a third of what the link takes).
-    const size_t chunk = (size_t)4 << 20;
+    // 4 MB chunks; a small input (one image) is cut in four so that its transfer, too, overlaps its staging
+    const size_t chunk = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)256 << 10, ((bytes / 4 + 65535) >> 16) << 16));
     const int nchunk = (int)((bytes + chunk - 1) / chunk);
-    const int nthreads = nchunk >= 4 ? 4 : (nchunk >= 2 ? 2 : 1);
+    const int nthreads = bytes >= ((size_t)16 << 20) ? 4 : (bytes >= ((size_t)8 << 20) ? 2 : 1);  // helpers only where they pay for their start
     std::vector<std::atomic<int>> done(nchunk);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     auto stage_chunks = [&](int first) {
