@@ -20,7 +20,11 @@ constexpr int kMaxDog = 10;
 constexpr int kMaxLev = kMaxDog + 2;
 constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH, ProgramCU.cu:42
 // streaming extrema scan (k_detect.hip): owned columns per strip, rows per wavefront segment
-constexpr int kStreamPitch = 124;
+#ifndef HESS_STREAM_NC
+#define HESS_STREAM_NC 2
+#endif
+constexpr int kStreamCols = HESS_STREAM_NC;        // columns per lane
+constexpr int kStreamPitch = 62 * kStreamCols;     // lanes 1..62 own columns, lanes 0 and 63 supply the halo
 #ifndef HESS_STREAM_ROWS
 #define HESS_STREAM_ROWS 24
 #endif

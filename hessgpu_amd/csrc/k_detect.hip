@@ -448,7 +448,10 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
 
 // ---- streaming extrema scan (pass 1, default for dog <= 5): registers instead of an LDS tile ----
 // One wavefront marches down a strip of 124 owned columns (lane j holds columns x0-2+2j, x0-1+2j of
-// every det-H level; lanes 0 and 63 only supply the halo column) over SX_ROWS rows.  Per new row and
+// every det-H level; lanes 0 and 63 only supply the halo column) over SX_ROWS rows.  (Columns per lane =
+// kStreamCols, hess_dev.h: with one column per lane the kernel needs 116 instead of 168 registers and runs four
+// instead of three wavefronts per SIMD, but spends 43 % more instructions per pixel on the neighbour exchange:
+// same time)  Per new row and
 // level it forms the horizontal 3-max / 3-min (neighbours from the adjacent lanes by DPP wave shifts)
 // and keeps them for the last three rows, so the 26-neighbour maximum of a pixel is
 //   max3( max over 3 rows of the level below, same of the level above,
@@ -468,6 +471,7 @@ template <int DOG>
 __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParams dp, const float* deth,
                                                              unsigned long long* rowmask, int* rowcnt) {
   constexpr int NLV = DOG + 2;
+  constexpr int NC = kStreamCols;  // columns per lane
   __shared__ uint32_t queue[4][SX_QCAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -480,25 +484,35 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
   const int ys = seg * SX_ROWS;
   if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
   const int ye = min(ys + SX_ROWS, og.h);
-  const int cx = strip * SX_PITCH - 2 + 2 * lane;  // this lane's first column (even)
-  const bool col_in = cx >= 0 && cx < og.wa;
+  const int cx = strip * SX_PITCH - NC + NC * lane;  // this lane's first column
+  const bool col_in = cx >= 0 && cx < og.wa;         // (wa is a multiple of 4: a lane's columns are all in or all out)
   const int wa = og.wa, h = og.h;
   const long long lstep = (long long)g.B * og.plane;
   const float* base = deth + og.lvl_off + (long long)b * og.plane;  // level l at base + l*lstep
   // a pixel is tested if it is interior (ProgramCU.cu:700-705) and owned by this lane
   const bool own = lane >= 1 && lane <= 62;
-  const bool cv0 = own && cx > 0 && cx < wa - 1;
-  const bool cv1 = own && cx + 1 > 0 && cx + 1 < wa - 1;
+  bool cv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) cv[c] = own && cx + c > 0 && cx + c < wa - 1;
   uint32_t* q = queue[wv];
   int qn = 0;
 
-  auto load_row = [&](int yy, float2 (&dst)[NLV]) {
+  struct Row { float v[NC]; };
+  auto load_row = [&](int yy, Row (&dst)[NLV]) {
     // rows/columns outside the plane are only ever neighbours of pixels that are not tested: any
     // finite value will do, so the address is clamped instead of the value being selected
     const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
     const long long off = (long long)yc * wa + (col_in ? cx : 0);
 #pragma unroll
-    for (int l = 0; l < NLV; l++) dst[l] = *reinterpret_cast<const float2*>(base + l * lstep + off);
+    for (int l = 0; l < NLV; l++) {
+      if (NC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(base + l * lstep + off);
+        dst[l].v[0] = t.x; dst[l].v[NC - 1] = t.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; c++) dst[l].v[c] = base[l * lstep + off + c];
+      }
+    }
   };
   auto process = [&](uint32_t e, bool active) {
     const int l = e >> 28, row = (e >> 14) & 0x3FFF, col = e & 0x3FFF;
@@ -512,24 +526,29 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
 
   // ring of the last three rows: horizontal 3-max/3-min of every level, raw centre values and
   // left/right max/min of the detection levels
-  float hmx[NLV][3][2], hmn[NLV][3][2];
-  float rc[DOG][3][2], lmx[DOG][3][2], lmn[DOG][3][2];
-  auto ingest = [&](const float2 (&cur)[NLV], int slot) {
+  float hmx[NLV][3][NC], hmn[NLV][3][NC];
+  float rc[DOG][3][NC], lmx[DOG][3][NC], lmn[DOG][3][NC];
+  auto ingest = [&](const Row (&cur)[NLV], int slot) {
 #pragma unroll
     for (int l = 0; l < NLV; l++) {
-      const float a0 = cur[l].x, a1 = cur[l].y;
-      const float L = lane_prev(a1), R = lane_next(a0);
-      hmx[l][slot][0] = max3f(L, a0, a1); hmx[l][slot][1] = max3f(a0, a1, R);
-      hmn[l][slot][0] = min3f(L, a0, a1); hmn[l][slot][1] = min3f(a0, a1, R);
-      if (l >= 1 && l <= DOG) {
-        rc[l - 1][slot][0] = a0; rc[l - 1][slot][1] = a1;
-        lmx[l - 1][slot][0] = fmaxf(L, a1); lmx[l - 1][slot][1] = fmaxf(a0, R);
-        lmn[l - 1][slot][0] = fminf(L, a1); lmn[l - 1][slot][1] = fminf(a0, R);
+      const float L = lane_prev(cur[l].v[NC - 1]), R = lane_next(cur[l].v[0]);
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const float left = c == 0 ? L : cur[l].v[c > 0 ? c - 1 : 0];
+        const float right = c == NC - 1 ? R : cur[l].v[c < NC - 1 ? c + 1 : c];
+        const float a = cur[l].v[c];
+        hmx[l][slot][c] = max3f(left, a, right);
+        hmn[l][slot][c] = min3f(left, a, right);
+        if (l >= 1 && l <= DOG) {
+          rc[l - 1][slot][c] = a;
+          lmx[l - 1][slot][c] = fmaxf(left, right);
+          lmn[l - 1][slot][c] = fminf(left, right);
+        }
       }
     }
   };
 
-  float2 cur[NLV], nxt[NLV];
+  Row cur[NLV], nxt[NLV];
   load_row(ys - 1, cur);
   load_row(ys, nxt);
   ingest(cur, 0);
@@ -551,11 +570,11 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
         load_row(y + 2, nxt);  // prefetch: consumed in the next iteration
         ingest(cur, sb);
         if (y > 0 && y < h - 1) {  // wavefront-uniform
-          float m9x[NLV][2], m9n[NLV][2];
+          float m9x[NLV][NC], m9n[NLV][NC];
 #pragma unroll
           for (int l = 0; l < NLV; l++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < NC; c++) {
               m9x[l][c] = max3f(hmx[l][sa][c], hmx[l][sc][c], hmx[l][sb][c]);
               m9n[l][c] = min3f(hmn[l][sa][c], hmn[l][sc][c], hmn[l][sb][c]);
             }
@@ -563,28 +582,30 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
 #pragma unroll
           for (int li = 0; li < DOG; li++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < NC; c++) {
               const int l = li + 1;
               const float r = rc[li][sc][c];
               const float nx = max3f(m9x[l - 1][c], m9x[l + 1][c], max3f(hmx[l][sa][c], hmx[l][sb][c], lmx[li][sc][c]));
               const float nn = min3f(m9n[l - 1][c], m9n[l + 1][c], min3f(hmn[l][sa][c], hmn[l][sb][c], lmn[li][sc][c]));
-              const bool f = (c ? cv1 : cv0) & (fabsf(r) > dp.thr0) & ((r >= nx) | (r <= nn));
-              cand |= f ? (1u << (li * 2 + c)) : 0u;
+              const bool f = cv[c] & (fabsf(r) > dp.thr0) & ((r >= nx) | (r <= nn));
+              cand |= f ? (1u << (li * NC + c)) : 0u;
             }
-          if (__any(cand != 0)) {
-            for (int k = 0; k < 2 * DOG; k++) {
-              const bool f = (cand >> k) & 1u;
-              const uint64_t m = __builtin_amdgcn_ballot_w64(f);
-              if (m == 0) continue;
-              if (f) q[qn + __popcll(m & ((1ull << lane) - 1ull))] =
-                  ((uint32_t)((k >> 1) + 1) << 28) | ((uint32_t)y << 14) | (uint32_t)(cx + (k & 1));
-              qn += __popcll(m);
-              if (qn >= 64) {
-                process(q[lane], true);
-                const uint32_t tail = q[64 + lane];
-                qn -= 64;
-                if (lane < qn) q[lane] = tail;
-              }
+          // queue the candidates: per trip every lane that still has one appends its lowest (a lane rarely has
+          // more than one per row, so this is one trip, not one per level and column; the order inside the queue
+          // does not matter -- accepted pixels set positional mask bits)
+          for (uint64_t m = __builtin_amdgcn_ballot_w64(cand != 0); m != 0; m = __builtin_amdgcn_ballot_w64(cand != 0)) {
+            if (cand != 0) {
+              const int k = __builtin_ctz(cand);
+              q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                  ((uint32_t)(k / NC + 1) << 28) | ((uint32_t)y << 14) | (uint32_t)(cx + k % NC);
+              cand &= cand - 1;
+            }
+            qn += __popcll(m);
+            if (qn >= 64) {
+              process(q[lane], true);
+              const uint32_t tail = q[64 + lane];
+              qn -= 64;
+              if (lane < qn) q[lane] = tail;
             }
           }
         }
