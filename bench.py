@@ -8,21 +8,33 @@
 Metric (BASELINE.json): Mpixels/s end-to-end (pyramid -> descriptor) on 1920x1080 images.
 Workload: BASELINE.json configs[1] -- 1920x1080 synthetic blobs, default octaves / DoG levels, top-K = 4096 -- as
 batches of `--batch` distinct images per GPU and step; for N > 1 this is configs[3] (a batch of 8 x N images sharded
-over N GPUs, 64 images at N = 8, RCCL gather of the feature lists to rank 0).  Per-GPU work is the same at every N
-(weak scaling).  A step = one pass of the hot path over one batch per GPU, the u8 luminance pixels already resident
-in HBM when the timed region starts; a step ends with the keypoints + descriptors of the batch in host memory
-(hess_wait returns) and, for N > 1, the gather.  `--contexts` contexts (streams) per GPU are pipelined.
+over N GPUs, 64 images at N = 8, RCCL gather of the feature lists to rank 0, landed in rank 0's host memory).  Per-GPU
+work is the same at every N (weak scaling).  A step = one pass of the hot path over one batch per GPU; `value` (=
+`value_device_resident`) is measured as the driver contract states it -- the u8 luminance pixels already resident in HBM
+when the timed region starts -- and a step ends with the keypoints + descriptors of the batch in host memory (hess_wait
+returns) and, for N > 1, the gathered lists in rank 0's host memory.  `--contexts` contexts (streams) per GPU are
+pipelined.
 
-Added to the contract's JSON line (rank 0, N = 1 unless noted):
-  roofline            the kernel that takes most device time per step, roofline_secondary the runner-up (descriptor
-                      and Gaussian kernels): algorithmic bytes per launch / average launch duration, measured with
-                      hipEvents on the context's stream in a single-stream leg of the same run; the descriptor entry
-                      also carries "valu": vector instructions per launch (PMC pass kept under profiles/) / duration
-                      against the issue peak 1024 SIMDs x 2.4 GHz / 2 cycles
+Added to the contract's JSON line (rank 0; N = 1 unless noted):
   value_host_to_host  the same steps starting from pinned HOST pixels (hess_submit_host: one asynchronous transfer per
                       batch, pipelined over the contexts) -- SURVEY 8(d)'s definition of the metric, PCIe included
-  latency_ms_single_image   one 1080p image, host pixels -> host results, one context (the drop-in RunSIFT call)
-  parity_checked      image 0 of the timed run compared bit for bit with the CPU oracle on the same pixels
+  value_device_resident   = value, under its own name
+  roofline            the kernel that takes most device time per step, roofline_secondary the runner-up (descriptor
+                      and Gaussian kernels): algorithmic bytes per launch / average launch duration, measured with
+                      hipEvents on the context's stream in a single-stream leg of the same run; each carries "valu":
+                      vector instructions per launch (PMC pass kept under profiles/) / duration against the NOMINAL
+                      issue peak (1024 SIMDs x 2.4 GHz / 2 cycles) and against the MEASURED sustained all-CU rate of
+                      tools/micro/valu_peak.hip (profiles/valu_peak.json)
+  latency_ms_single_image   one 1080p image, pageable host pixels -> host results, one context (the C-ABI call under
+                      the drop-in RunSIFT)
+  value_siftgpu_api_1thread / value_siftgpu_api_threads   the reference's own calling pattern through libsiftgpu.so:
+                      RunSIFT(w, h, data, GL_LUMINANCE, GL_UNSIGNED_BYTE) + GetFeatureVector per image, one instance
+                      (speed.cpp:107-124) and one instance per host thread (MultiThreadSIFT.cpp:83-156,231-244), run
+                      by apps/multithread.cpp -mem as a child process after the timed region
+  configs4            BASELINE.json configs[4] (one 4096x4096 image, -maxd 4096 -topk 65536 -half) after the timed
+                      region: Mpix/s with one and with three contexts, features, its descriptor launch's roofline entry
+  parity_checked      image 0 of the timed run (N > 1: image 0 of every rank, from the gathered lists) compared bit for
+                      bit with the CPU oracle on the same pixels
   cpu_baseline        the CPU oracle (a port of the reference's CUDA path; the reference has no CPU path) timed on
                       rank 0's host cores on a bounded sample of the same workload
 """
@@ -38,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H, TOPK = 1920, 1080, 4096
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_GINST = 1024 * 2.4 / 2.0     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0     # nominal: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
 def main():
@@ -52,9 +64,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")
+    ap.add_argument("--no-api-leg", action="store_true", help="skip the libsiftgpu.so (RunSIFT + GetFeatureVector) legs")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the 4096x4096 leg (BASELINE.json configs[4])")
+    ap.add_argument("--api-threads", type=int, default=4, help="SiftGPU instances (host threads) of the multi-instance leg")
+    ap.add_argument("--gather-dest", choices=("host", "hbm"), default="host",
+                    help="N > 1: where the gathered feature lists end on rank 0 (host = pinned host memory, like N = 1)")
     ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "
                     "the headline workload uses the default (all 7 octaves of 1920x1080)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU: keep this rank's host threads on the CPUs next to its GPU -- before any GPU call, so that
+    # the runtime's threads and pinned allocations inherit the binding (one rank alone on a node keeps all its CPUs)
+    bound = None
+    if world > 1 or os.environ.get("HESS_BENCH_FORCE_DIST") == "1":
+        from hessgpu_amd import numa
+        bound = numa.bind_to_gpu(local_rank)
 
     import numpy as np
     import torch
@@ -63,9 +90,6 @@ def main():
     import hessgpu_amd
     from hessgpu_amd import _abi, dist as hdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -112,13 +136,19 @@ def main():
             for _ in range(nctx)]
     for c in ctxs:
         c.reserve(W, H, B)
+    landing = hdist.HostLanding() if (use_dist and args.gather_dest == "host") else None
+    gathered = {}
 
     def finish(c):
         c.wait()
         counts = [c.count(b) for b in range(B)]
         if use_dist:
             keys, desc = hdist.device_feature_tensors(c, counts, dev)
-            hdist.gather_feature_lists(counts, keys, desc, dst=0)
+            allc, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0)
+            if rank == 0:
+                if landing is not None:   # the other ranks' lists into pinned host memory: the step ends where N = 1 ends
+                    gk, gd = landing.land(gk, gd, own_rank=0)
+                gathered["counts"], gathered["keys"], gathered["desc"] = allc, gk, gd
         return counts
 
     def run_steps(n, submit):
@@ -156,11 +186,18 @@ def main():
     last = ctxs[(args.steps - 1) % nctx]          # context that ran the last timed step: its results are still there
     timed_k0, timed_d0 = last.fetch(0)            # image 0 of the timed run (parity_checked below)
     timed_keys = [last.fetch(b)[0] for b in range(B)]
+    # N > 1: image 0 of every other rank out of the gathered lists of the last timed step (rank 0 checks them below)
+    gathered_first = {}
+    if use_dist and rank == 0 and gathered:
+        for r in range(1, world):
+            n0 = gathered["counts"][r][0]
+            gathered_first[r] = (gathered["keys"][r][:n0].cpu().numpy().copy(),
+                                 gathered["desc"][r][:n0].cpu().numpy().copy())
 
     # Legs outside the timed region (rank 0 alone reports them; every rank runs the device ones to stay in step).
     # Roofline leg: per-kernel hipEvent durations are only meaningful when kernels of different streams do not
     # overlap, so the events are recorded in a separate single-stream leg of the same run (same batch, one context).
-    prof, prof_dev, roof_steps = None, None, 0
+    prof, prof_mirror, roof_steps = None, None, 0
     if not args.no_profile:
         c = ctxs[0]
         roof_steps = max(3, min(args.steps, 10))
@@ -170,28 +207,37 @@ def main():
             c.run_device(d_imgs.data_ptr(), B, H, W)
         prof = c.profile()
         c.profile_enable(False)
-        # The shipped descriptor launch also stores its 536 B per feature into pinned host memory (posted PCIe
-        # writes); alone on the device it then waits for the link.  The same leg on a context that delivers by a
-        # copy after the kernels shows the kernel's own duration.
-        saved = os.environ.get("HESS_HOST_DIRECT")
-        os.environ["HESS_HOST_DIRECT"] = "0"
+        # For comparison, the same leg with the other form of the descriptor launch: descriptor_kernel<true> also
+        # stores the results into pinned host memory (what batches of one or two images use by default; alone on the
+        # device it waits for PCIe), descriptor_kernel<false> leaves them in HBM for the copier thread's DMA copy.
+        saved = os.environ.get("HESS_DELIVERY")
+        os.environ["HESS_DELIVERY"] = "dma" if _mirror_is_default(B) else "mirror"   # the other form
         cd = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
                                      octave_num=args.octaves)
         if saved is None:
-            del os.environ["HESS_HOST_DIRECT"]
+            del os.environ["HESS_DELIVERY"]
         else:
-            os.environ["HESS_HOST_DIRECT"] = saved
+            os.environ["HESS_DELIVERY"] = saved
         cd.reserve(W, H, B)
         cd.run_device(d_imgs.data_ptr(), B, H, W)
         cd.profile_enable(True)
         cd.profile_reset()
         for _ in range(roof_steps):
             cd.run_device(d_imgs.data_ptr(), B, H, W)
-        prof_dev = cd.profile()
+        prof_mirror = cd.profile()
         cd.close()
     host = None
     if world == 1 and not use_dist and not args.no_host_leg:
         host = host_legs(ctxs, nctx, imgs, B, args, run_steps, fence, torch)
+    for c in ctxs:
+        c.close()
+    ctxs = []
+    cfg4 = None
+    if world == 1 and not use_dist and not args.no_configs4:
+        cfg4 = configs4_leg(local_rank, torch)
+    api = None
+    if world == 1 and not use_dist and not args.no_api_leg:
+        api = api_legs(imgs[0], args.api_threads)
 
     if rank == 0:
         pixels = float(world) * B * args.steps * W * H
@@ -222,12 +268,20 @@ def main():
                 "distinct_images_per_gpu": nd,
                 "features_per_image_mean": round(float(np.mean(counts)), 1),
                 "sharding": (f"images over {world} rank(s), exact-size RCCL send/recv of the feature lists to rank 0"
+                             + (", landed in rank 0's pinned host memory" if landing is not None else " (HBM)")
                              if use_dist else "single GPU"),
                 "input": "u8 luminance resident in HBM; results delivered to host memory",
+                "result_delivery": "copier thread: DMA copy of the exact byte count, no dependency on a kernel "
+                                   "(batches of 1-2 images: stores of the descriptor kernel into pinned memory)",
             },
+            "value_device_resident": round(value, 2),
+            "value_definition": "driver contract: pixels resident in HBM when the timed region starts, results in host "
+                                "memory when a step ends; value_host_to_host is the same from pinned host pixels (SURVEY 8d)",
         }
+        if bound is not None:
+            out["config"]["cpu_binding"] = f"{len(bound)} CPUs local to the rank's GPU"
         if prof is not None:
-            roofs = rooflines(prof, roof_steps, timed_keys, B, prof_dev)
+            roofs = rooflines(prof, roof_steps, timed_keys, B, prof_mirror, _mirror_is_default(B))
             ranked = sorted(roofs, key=lambda r: -r["ms_per_step"])
             if ranked:
                 out["roofline"] = ranked[0]
@@ -237,15 +291,24 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"]}
         if host is not None:
             out.update(host)
-        if world == 1 and not args.no_cpu_baseline:
-            out["parity_checked"] = parity_check(imgs[0], timed_k0, timed_d0)
-            out["cpu_baseline"] = cpu_baseline(imgs[:min(nd, 4)])
+        if api is not None:
+            out.update(api)
+        if cfg4 is not None:
+            out["configs4"] = cfg4
+        if not args.no_cpu_baseline:
+            ok = parity_check(imgs[0], timed_k0, timed_d0)
+            for r, (gk, gd) in gathered_first.items():   # N > 1: image 0 of every rank, from the gathered lists
+                ref_img = fixtures.synthetic_blobs(W, H, r * B)
+                ok = ok and parity_check(ref_img, np.frombuffer(gk.tobytes(), dtype=_abi.KEYPOINT_DTYPE), gd)
+            out["parity_checked"] = ok
+            if use_dist:
+                out["parity_checked_ranks"] = 1 + len(gathered_first)
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(imgs[:min(nd, 4)])
         if json_fd is None:
             print(json.dumps(out), flush=True)
         else:
             os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for c in ctxs:
-        c.close()
     if use_dist:
         tdist.barrier()
         tdist.destroy_process_group()
@@ -283,8 +346,123 @@ def host_legs(ctxs, nctx, imgs, B, args, run_steps, fence, torch):
     }
 
 
-def rooflines(prof, steps, timed_keys, images, prof_dev=None):
-    """Roofline entries of the two heavy kernels from the single-stream profile leg."""
+def api_legs(img0, nthreads):
+    """The reference's own calling pattern through libsiftgpu.so (RunSIFT(w,h,data,GL_LUMINANCE,GL_UNSIGNED_BYTE) +
+    GetFeatureVector per image): one instance, and one instance per host thread on the device -- apps/multithread.cpp
+    -mem as a child process (this process no longer holds a context)."""
+    import re
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "hessgpu_amd", "bin", "multithread")
+    if not os.path.exists(exe):
+        return {"value_siftgpu_api_1thread": None, "value_siftgpu_api_threads": None, "siftgpu_api": f"{exe} not built"}
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        pgm = os.path.join(td, "bench.pgm")
+        with open(pgm, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (img0.shape[1], img0.shape[0]))
+            f.write(img0.tobytes())
+        for key, k, reps in (("value_siftgpu_api_1thread", 1, 200), ("value_siftgpu_api_threads", nthreads, 150)):
+            r = subprocess.run([exe, "-i", pgm, "-mem", "-n", str(reps), "-devices", "1", "-per-device", str(k),
+                                "-topk", str(TOPK)], capture_output=True, text=True, timeout=300)
+            m = re.search(r"MPIX: ([0-9.]+)", r.stdout)
+            out[key] = float(m.group(1)) if (m and r.returncode == 0) else None
+            if out[key] is None:
+                print("bench.py: multithread failed:", r.stdout[-500:], r.stderr[-500:], file=sys.stderr)
+    out["siftgpu_api"] = (f"libsiftgpu.so, RunSIFT(w,h,data,GL_LUMINANCE,GL_UNSIGNED_BYTE) + GetFeatureVector per 1080p image "
+                          f"(pageable pixels in, caller's arrays out), -topk {TOPK}; threads leg: {nthreads} instances, "
+                          "one per host thread (MultiThreadSIFT.cpp pattern)")
+    return out
+
+
+def configs4_leg(local_rank, torch):
+    """BASELINE.json configs[4]: one 4096x4096 synthetic image, -maxd 4096 -topk 65536 -half (64-d descriptors),
+    device-resident input, results to host memory; one context synchronously and three contexts pipelined, plus the
+    roofline entry of its descriptor launch (single-stream hipEvents)."""
+    import numpy as np
+
+    import fixtures
+    import hessgpu_amd
+    from hessgpu_amd import _abi
+
+    S = 4096
+    img = fixtures.synthetic_blobs(S, S, 0)   # the generator scales its blob count with the area
+    d = torch.from_numpy(img[None]).to(torch.device("cuda", local_rank))
+    ctxs = [hessgpu_amd.HessContext(local_rank, tex_max_dim=4096, half_sift=1, truncate_method=_abi.TRUNC_TOPK,
+                                    feature_count_threshold=65536) for _ in range(3)]
+    for c in ctxs:
+        c.reserve(S, S, 1)
+        c.run_device(d.data_ptr(), 1, S, S)
+    n = ctxs[0].count(0)
+    keys = ctxs[0].fetch(0)[0]
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctxs[0].run_device(d.data_ptr(), 1, S, S)
+    lat = (time.perf_counter() - t0) / reps
+    steps, inflight = 30, []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        c = ctxs[i % 3]
+        if len(inflight) == 3:
+            inflight.pop(0).wait()
+        c.submit_device(d.data_ptr(), 1, S, S)
+        inflight.append(c)
+    while inflight:
+        inflight.pop(0).wait()
+    dt = (time.perf_counter() - t0) / steps
+    c = ctxs[0]
+    c.profile_enable(True)
+    c.profile_reset()
+    for _ in range(5):
+        c.run_device(d.data_ptr(), 1, S, S)
+    prof = c.profile()
+    for c in ctxs:
+        c.close()
+    dk = prof["descriptor"]
+    dur = dk["ms"] * 1e-3 / max(1, dk["launches"])
+    s_oct = keys["s"].astype(np.float64) / (2.0 ** (keys["level"] // 3))
+    fbytes = float(np.sum((15.0 * s_oct) ** 2 * 8.0 + 16.0 + 24.0 + 256.0))
+    return {
+        "workload": "4096x4096 synthetic blobs, -maxd 4096 -topk 65536 -half (64-d descriptors) [configs[4]]",
+        "features": n,
+        "Mpix_per_s_one_context": round(S * S / lat / 1e6, 1), "ms_per_image_one_context": round(lat * 1e3, 3),
+        "Mpix_per_s_three_contexts": round(S * S / dt / 1e6, 1), "ms_per_image_three_contexts": round(dt * 1e3, 3),
+        "kernel_ms_per_image": {k: round(v["ms"] / 5, 4) for k, v in prof.items() if v["launches"]},
+        "roofline_descriptor": {
+            "bound": "hbm", "kernel": "descriptor_kernel<false> (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / dur / 1e9 / HBM_PEAK_GBS, 4),
+            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1), "features_per_launch": n,
+        },
+    }
+
+
+def _valu_entry(rate, insts, unit_key, source):
+    """Vector-issue entry: the kernel's instruction rate against the nominal peak and against the all-CU rate this
+    chip sustains for plain v_fma_f32 (tools/micro/valu_peak.hip -> profiles/valu_peak.json): the clock under an
+    all-CU vector load is below the nominal 2.4 GHz, so the two fractions differ."""
+    e = {"bound": "valu", "achieved": round(rate, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
+         "frac": round(rate / VALU_PEAK_GINST, 4), unit_key: insts, "source": source}
+    measured = _profile_value("valu_peak.json", "sustained_fma_ginst_all_cus")
+    if measured:
+        e["peak_measured"] = measured
+        e["frac_of_measured"] = round(rate / measured, 4)
+    return e
+
+
+def _mirror_is_default(batch):
+    """Whether a batch of this size is delivered by the descriptor kernel's own host stores (hess_pipeline.hip,
+    choose_delivery): HESS_DELIVERY overrides, else batches up to HESS_MIRROR_MAX_BATCH (2)."""
+    pref = os.environ.get("HESS_DELIVERY")
+    if pref in ("mirror", "dma", "blit"):
+        return pref == "mirror"
+    return batch <= int(os.environ.get("HESS_MIRROR_MAX_BATCH", "2"))
+
+
+def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
+    """Roofline entries of the two heavy kernels from the single-stream profile leg (prof); prof_other: the same leg
+    with the other form of the descriptor launch."""
     import numpy as np
 
     out = []
@@ -303,10 +481,9 @@ def rooflines(prof, steps, timed_keys, images, prof_dev=None):
         gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
         if gi:
             rate = gi * images * steps / (g["ms"] * 1e-3) / 1e9
-            out[-1]["valu"] = {"bound": "valu", "achieved": round(rate, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
-                               "frac": round(rate / VALU_PEAK_GINST, 4), "instructions_per_image": gi,
-                               "source": "SQ_INSTS_VALU of the PMC pass in profiles/gauss_traffic.json x images of this run "
-                                         "(about half are packed-FP32 or division/sqrt helper instructions that issue at half rate or less)"}
+            out[-1]["valu"] = _valu_entry(rate, gi, "instructions_per_image",
+                                          "SQ_INSTS_VALU of the PMC pass in profiles/gauss_traffic.json x images of this run "
+                                          "(about half are packed-FP32 or division/sqrt helper instructions that issue at half rate or less)")
     d = prof["descriptor"]
     if d["launches"]:
         # algorithmic bytes of one launch (per output feature): the rotated 5x5-cell footprint of side
@@ -319,9 +496,13 @@ def rooflines(prof, steps, timed_keys, images, prof_dev=None):
             nfeat += len(k)
         dur = d["ms"] * 1e-3 / d["launches"]
         achieved = fbytes / dur / 1e9
+        names = {False: "descriptor_kernel<false> (one wavefront per feature: rotated-grid histogram + normalisation + packed "
+                        "result stores in HBM; the copier thread's DMA copy takes them to the host)",
+                 True: "descriptor_kernel<true> (one wavefront per feature: rotated-grid histogram + normalisation + result "
+                       "stores incl. the pinned host mirror)"}
         e = {
             "bound": "hbm",
-            "kernel": "descriptor_kernel<true> (one wavefront per feature: rotated-grid histogram + normalisation + result stores incl. the pinned host mirror)",
+            "kernel": names[mirror],
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profile_value("descriptor_counters.json", "hbm_bytes_per_launch"),
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1),
@@ -329,22 +510,18 @@ def rooflines(prof, steps, timed_keys, images, prof_dev=None):
         }
         insts = _profile_value("descriptor_counters.json", "valu_insts_per_feature")
         if insts:
-            rate = insts * nfeat / dur / 1e9
-            e["valu"] = {"bound": "valu", "achieved": round(rate, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
-                         "frac": round(rate / VALU_PEAK_GINST, 4), "instructions_per_feature": insts,
-                         "source": "SQ_INSTS_VALU of the PMC pass in profiles/descriptor_counters.json x features of this run"}
-        dd = (prof_dev or {}).get("descriptor")
+            e["valu"] = _valu_entry(insts * nfeat / dur / 1e9, insts, "instructions_per_feature",
+                                    "SQ_INSTS_VALU of the PMC pass in profiles/descriptor_counters.json x features of this run")
+        dd = (prof_other or {}).get("descriptor")
         if dd and dd["launches"]:
             ddur = dd["ms"] * 1e-3 / dd["launches"]
-            e["without_host_mirror"] = {
+            e["without_host_mirror" if mirror else "with_host_mirror"] = {
                 "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(fbytes / ddur / 1e9, 1), "unit": "GB/s",
-                "kernel": "descriptor_kernel<false>",
-                "note": "same launch on a context that delivers results by a copy after the kernels (HESS_HOST_DIRECT=0): "
-                        "the shipped launch also stores keypoints + descriptors into pinned host memory and, alone "
-                        "on the device, waits for PCIe",
+                "kernel": "descriptor_kernel<false>" if mirror else "descriptor_kernel<true>",
+                "note": "same launch on a context created with HESS_DELIVERY=" + ("dma" if mirror else "mirror") +
+                        ": descriptor_kernel<true> also stores keypoints + descriptors into pinned host memory and, "
+                        "alone on the device, waits for PCIe",
             }
-            if insts:
-                e["without_host_mirror"]["valu_frac"] = round(insts * nfeat / ddur / 1e9 / VALU_PEAK_GINST, 4)
         out.append(e)
     return out
 

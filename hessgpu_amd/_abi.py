@@ -7,7 +7,7 @@ CPU oracle's `hess_cpu_` entry points with the same table so both sides read ali
 """
 import ctypes as C
 
-HESS_ABI_VERSION = 1
+HESS_ABI_VERSION = 2
 
 HESS_OK = 0
 HESS_ERR_ARG = -1
@@ -57,8 +57,7 @@ class HessParams(C.Structure):
         ("auto_downscale", C.c_int32),
         ("verbose", C.c_int32),
         ("dynamic_indexing", C.c_int32),
-        ("detector", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("reserved", C.c_int32 * 7),   # must be zero for the product (word 0: the test oracle's detector switch)
     ]
 
 
@@ -123,6 +122,8 @@ PRODUCT_PROTOTYPES = {
     "profile_enable": (C.c_int, [_ctx, C.c_int]),
     "profile_get": (C.c_int, [_ctx, C.c_int, _P(C.c_double), _P(C.c_longlong), _P(C.c_double)]),
     "profile_reset": (C.c_int, [_ctx]),
+    "debug_regrown": (C.c_int, [_ctx]),
+    "last_input": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
 }
 
 

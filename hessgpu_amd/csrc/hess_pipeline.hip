@@ -13,10 +13,12 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -60,6 +62,33 @@ struct PendingRun {
   bool timed_load;  // ev_load[] bracket a host->device transfer of this batch
 };
 
+// Result delivery ("Result delivery and PCIe").  Three ways for the packed keypoints and
+// descriptors of a batch to reach pinned host memory:
+//   kDeliverMirror  the descriptor kernel stores them into the pinned buffers as well (posted PCIe writes out of the
+//                   kernel): no command after the kernels, the shortest path for one image -- but a kernel that waits
+//                   for the link holds up the memory path of whatever runs beside it;
+//   kDeliverDma     a per-context copier thread waits on the host for the event behind the descriptor kernel, reads
+//                   the exact byte count from the pinned count block and issues the copy on a stream that never
+//                   carries a kernel and has no dependency on one: the runtime then uses the DMA engine (a
+//                   device->host copy that FOLLOWS kernels in stream order is executed as a blit kernel instead,
+//                   which is the same PCIe-bound shader copy as the mirror); hess_wait waits for that copy;
+//   kDeliverBlit    hipMemcpyAsync on the context's stream after hess_wait has read the counts (the fallback, and
+//                   what the reference does per level, PyramidCU.cpp:509-532).
+enum { kDeliverMirror = 0, kDeliverDma = 1, kDeliverBlit = 2 };
+
+struct Copier {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool started = false, stop = false, has_job = false, done = true;
+  int batch = 0;
+  int rc = 0;            // result of the last job (hess_status)
+  bool overflow = false; // the batch overflowed its feature storage: nothing was copied
+  std::string err;
+  hipStream_t cs = nullptr;     // copy-only stream
+  hipEvent_t ev_done = nullptr; // recorded on the context's stream behind the last kernel of a batch
+};
+
 struct hess_ctx {
   int device = 0;
   hipStream_t st = nullptr;
@@ -90,9 +119,17 @@ struct hess_ctx {
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
   DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
+  size_t last_input_bytes = 0;     // bytes of the last batch handed over by hess_submit_host (still in `stage`)
   hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
   // results written by the descriptor kernel straight into the pinned host buffers (no D2H pass after it)
-  bool host_direct = false, host_direct_allowed = true;
+  bool host_direct = false;        // delivery == kDeliverMirror for the submitted batch
+  bool host_fits = false;          // the pinned result buffers hold the worst case of the current plan
+  int delivery = kDeliverMirror;   // of the submitted batch (choose_delivery)
+  int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
+  int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
+  int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
+  int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
+  Copier cp;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
   // user-supplied keypoint list (SiftPyramid::SetKeypointList): used by the next run, then cleared
   std::vector<hess_keypoint> user_keys;
@@ -142,14 +179,14 @@ void set_err(hess_ctx* c, const char* fmt, ...) {
 
 int ensure(hess_ctx* c, DevBuf& b, size_t bytes, bool pinned_host = false) {
   if (bytes <= b.bytes) return 0;
-  if (b.p) {
-    if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
-  }
-  size_t want = bytes + bytes / 8;  // slack so slightly larger inputs do not reallocate
-  if (pinned_host) HIP_TRY(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
-  else HIP_TRY(c, hipMalloc(&b.p, want));
+  // the new buffer first: when the allocation fails the old one is still there (a context survives a refused
+  // hess_reserve)
+  const size_t want = bytes + bytes / 8;  // slack so slightly larger inputs do not reallocate
+  void* np = nullptr;
+  if (pinned_host) HIP_TRY(c, hipHostMalloc(&np, want, hipHostMallocDefault));
+  else HIP_TRY(c, hipMalloc(&np, want));
+  if (b.p) { if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+  b.p = np;
   b.bytes = want;
   return 0;
 }
@@ -254,7 +291,7 @@ int fmt_channels(int format) {
 }
 
 // Geometry: SetImageData (GLTexImage.cpp:932-1033) + InitPyramid/ResizePyramid (PyramidCU.cpp:113-310).
-int plan(hess_ctx* c, int width, int height, int batch) {
+int plan_inner(hess_ctx* c, int width, int height, int batch) {
   const hess_params& p = c->p;
   int ds = 0, ws = width, hs = height;
   if (p.first_octave > 0) { ds = p.first_octave; ws = width >> ds; hs = height >> ds; }
@@ -317,6 +354,7 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   c->dim = p.compute_descriptors ? (p.half_sift ? 64 : 128) : 0;
   long long det_px = gt / B;  // detection pixels per image
   int cap_raw = (int)(det_px / 32 < 16384 ? 16384 : det_px / 32);
+  if (c->cap_init > 0) cap_raw = c->cap_init;  // developer switch: start small so that the grow-and-re-run path is taken
   if (cap_raw < c->cap_raw) cap_raw = c->cap_raw;
   if (cap_raw < (int)(2 * c->user_keys.size() + 8)) cap_raw = (int)(2 * c->user_keys.size() + 8);
   int cap_sel = c->use_topk ? p.feature_count_threshold : cap_raw;
@@ -364,12 +402,11 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   if (c->dim && (rc = ensure(c, c->desc, (size_t)B * cap_feat * c->dim * 4))) return rc;
   if ((rc = ensure(c, c->h_small, (size_t)(3 * B + 8) * 4, true))) return rc;
   {
-    // The descriptor kernel can store its packed results into host memory as well (posted PCIe writes that
-    // overlap the kernel itself): then no device->host pass follows the kernels.  Only while the worst-case
-    // result size stays moderate: the pinned buffers must hold B * cap_feat records up front.
+    // The pinned result buffers hold the worst case B * cap_feat records up front while that stays moderate; beyond
+    // it they grow on demand once the counts are known (wait_impl / the copier), and the in-kernel mirror is not used.
     const size_t host_bytes = (size_t)B * cap_feat * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
-    c->host_direct = c->host_direct_allowed && host_bytes <= ((size_t)512 << 20);
-    if (c->host_direct) {
+    c->host_fits = host_bytes <= ((size_t)512 << 20);
+    if (c->host_fits) {
       if ((rc = ensure(c, c->h_keys, (size_t)B * cap_feat * sizeof(HostKeypoint), true))) return rc;
       if (c->dim && (rc = ensure(c, c->h_desc, (size_t)B * cap_feat * c->dim * 4, true))) return rc;
     }
@@ -389,6 +426,17 @@ int plan(hess_ctx* c, int width, int height, int batch) {
   c->has_taps0 = s0 > 0.0f;
   if (c->has_taps0) make_taps(p, s0, &c->taps0);
   return 0;
+}
+
+// A plan that fails half way (an allocation was refused) leaves buffers of mixed sizes behind: the next run plans
+// again from scratch (buffers that are large enough are kept), so the context stays usable.
+int plan(hess_ctx* c, int width, int height, int batch) {
+  const int rc = plan_inner(c, width, height, batch);
+  if (rc) {
+    c->planned = false;
+    (void)hipGetLastError();  // the refused allocation must not be reported by the next call's error check
+  }
+  return rc;
 }
 
 // ---- profiling helpers ----
@@ -411,11 +459,11 @@ struct ProfScope {
       on = false;
       return;
     }
-    (void)hipEventRecord(ep.a, c->st);
+    if (hipEventRecord(ep.a, c->st) != hipSuccess) { c->pool.push_back(ep.a); c->pool.push_back(ep.b); on = false; }
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(ep.b, c->st);
+    if (hipEventRecord(ep.b, c->st) != hipSuccess) { c->pool.push_back(ep.a); c->pool.push_back(ep.b); return; }
     c->pending.push_back(ep);
   }
 };
@@ -451,7 +499,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   float* got = (float*)c->got.p;
   auto plane_ptr = [&](float* base, int o, int l) { return base + g.o[o].lvl_off + (long long)l * g.B * g.o[o].plane; };
 
-  (void)hipEventRecord(c->ev[0], st);
+  HIP_TRY(c, hipEventRecord(c->ev[0], st));
   const bool user_mode = !c->user_keys.empty();
   if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
   // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
@@ -484,7 +532,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         else
           launch_gauss(st, src_f, nullptr, og.wa, og.plane, plane_ptr(gauss, 0, 0), og.wa, og.h, batch, c->taps0);
       } else {
-        (void)hipMemcpyAsync(plane_ptr(gauss, 0, 0), src_f, (size_t)batch * og.plane * 4, hipMemcpyDeviceToDevice, st);
+        HIP_TRY(c, hipMemcpyAsync(plane_ptr(gauss, 0, 0), src_f, (size_t)batch * og.plane * 4, hipMemcpyDeviceToDevice, st));
       }
     } else if (!fused_decim) {
       ProfScope ps(c, HESS_K_DOWNSAMPLE, (double)batch * og.plane * 8.0);
@@ -504,7 +552,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                    decim ? plane_ptr(gauss, o + 1, 0) : nullptr, decim ? g.o[o + 1].wa : 0, decim ? g.o[o + 1].h : 0);
     }
   }
-  (void)hipEventRecord(c->ev[1], st);
+  HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
   {  // the octaves' top levels have no successor blur: one standalone launch for all of them
     double px = 0;
@@ -534,7 +582,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
     launch_extrema_mark(st, g, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
   }
-  (void)hipEventRecord(c->ev[2], st);
+  HIP_TRY(c, hipEventRecord(c->ev[2], st));
   launch_row_scan(st, g, lp, (const int*)c->rowcnt.p, (int*)c->rowoff.p, (int*)c->level_count.p,
                   (int*)c->raw_total.p, c->cap_raw, (int*)c->overflow.p, batch);
   {
@@ -543,7 +591,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                            (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch,
                            c->use_topk ? (unsigned*)c->hist.p : nullptr, p.feature_count_threshold);
   }
-  (void)hipEventRecord(c->ev[3], st);
+  HIP_TRY(c, hipEventRecord(c->ev[3], st));
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
   const RawKey* list = (const RawKey*)c->raw.p;
   const int* list_total = (const int*)c->raw_total.p;
@@ -560,7 +608,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   c->d_list = list;
   c->d_list_total = list_total;
   c->cap_list = cap_list;
-  (void)hipEventRecord(c->ev[4], st);
+  HIP_TRY(c, hipEventRecord(c->ev[4], st));
   // ---- orientation (GetFeatureOrientations) ----
   OrientParams op;
   op.gaussian_factor = p.orient_gaussian_factor;
@@ -575,12 +623,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_ORIENT, 0.0);
     launch_orientation(st, g, op, list, list_total, cap_list, got, (FRec*)c->recs.p, (int*)c->ocount.p, batch);
   }
-  (void)hipEventRecord(c->ev[5], st);
+  HIP_TRY(c, hipEventRecord(c->ev[5], st));
   // ---- multi-orientation expansion (ReshapeFeatureListCPU) ----
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
                       (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
-                      (int*)c->overflow.p, (int*)c->img_base.p, c->host_direct ? (int*)c->h_small.p : nullptr, batch);
-  (void)hipEventRecord(c->ev[6], st);
+                      (int*)c->overflow.p, (int*)c->img_base.p, (int*)c->h_small.p, batch);
+  HIP_TRY(c, hipEventRecord(c->ev[6], st));
   // ---- descriptors (GetFeatureDescriptors) ----
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
@@ -599,7 +647,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                       (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                       (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, batch);
   }
-  (void)hipEventRecord(c->ev[7], st);
+  HIP_TRY(c, hipEventRecord(c->ev[7], st));
   return 0;
 }
 
@@ -677,7 +725,7 @@ int enqueue_user(hess_ctx* c) {
   c->d_list = list;
   c->d_list_total = list_total;
   c->cap_list = c->cap_raw;
-  for (int e = 1; e <= 4; e++) (void)hipEventRecord(c->ev[e], st);
+  for (int e = 1; e <= 4; e++) HIP_TRY(c, hipEventRecord(c->ev[e], st));
   float* got = (float*)c->got.p;
   if (!c->user_have_orientation) {
     OrientParams op;
@@ -691,14 +739,14 @@ int enqueue_user(hess_ctx* c) {
     for (int l = 0; l < kMaxLev; l++) op.level_sigma[l] = l <= s.level_max ? s.level_sigma[l] : 0.0f;
     launch_orientation(st, g, op, list, list_total, c->cap_raw, got, (FRec*)c->recs.p, (int*)c->ocount.p, 1);
   }
-  (void)hipEventRecord(c->ev[5], st);
+  HIP_TRY(c, hipEventRecord(c->ev[5], st));
   LimitParams lp;
   lp.method = 0;
   lp.threshold = -1;  // LimitFeatureCount returns at once for existing keypoints (SiftPyramid.cpp:203)
   launch_feature_scan(st, g, lp, 0, list, list_total, c->cap_raw, (const int*)c->ocount.p, (int*)c->foffset.p,
                       (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
-                      (int*)c->overflow.p, (int*)c->img_base.p, c->host_direct ? (int*)c->h_small.p : nullptr, 1);
-  (void)hipEventRecord(c->ev[6], st);
+                      (int*)c->overflow.p, (int*)c->img_base.p, (int*)c->h_small.p, 1);
+  HIP_TRY(c, hipEventRecord(c->ev[6], st));
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
   dsp.half_sift = p.half_sift;
@@ -713,11 +761,106 @@ int enqueue_user(hess_ctx* c) {
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
-  (void)hipEventRecord(c->ev[7], st);
+  HIP_TRY(c, hipEventRecord(c->ev[7], st));
   return 0;
 }
 
-// Enqueue the whole path and the copy of the per-image counts; returns without waiting.
+// ---- copier thread (kDeliverDma) ----
+// One job at a time: wait on the host for the event behind the batch's last kernel, read the packed total from the
+// pinned count block (stored there by feature_scan_kernel), copy exactly that many records on the copy-only stream.
+void copier_main(hess_ctx* c) {
+  Copier& cp = c->cp;
+  (void)hipSetDevice(c->device);
+  std::unique_lock<std::mutex> lk(cp.mu);
+  for (;;) {
+    cp.cv.wait(lk, [&] { return cp.stop || cp.has_job; });
+    if (cp.stop) return;
+    const int batch = cp.batch;
+    lk.unlock();
+    int rc = 0;
+    bool overflow = false;
+    char msg[256] = "";
+    auto fail = [&](const char* what, hipError_t e) {
+      snprintf(msg, sizeof(msg), "%s failed: %s (copier)", what, hipGetErrorString(e));
+      rc = e == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;
+    };
+    hipError_t e = hipEventSynchronize(cp.ev_done);
+    if (e != hipSuccess) fail("hipEventSynchronize", e);
+    if (!rc) {
+      const int* hs = (const int*)c->h_small.p;
+      overflow = hs[batch + 1] != 0 || hs[batch + 2] != 0;
+      const size_t total = overflow ? 0 : (size_t)hs[batch];
+      if (total) {
+        // (the pinned buffers hold the worst case unless that exceeds 512 MB: then they grow here, rarely)
+        DevBuf *hk = &c->h_keys, *hd = &c->h_desc;
+        if (hk->bytes < total * sizeof(HostKeypoint) || (c->dim && hd->bytes < total * c->dim * 4)) {
+          if (ensure(c, *hk, total * sizeof(HostKeypoint), true) || (c->dim && ensure(c, *hd, total * c->dim * 4, true))) {
+            snprintf(msg, sizeof(msg), "pinned result buffers: allocation failed (copier)");
+            rc = HESS_ERR_NOMEM;
+          }
+        }
+        if (!rc && (e = hipMemcpyAsync(hk->p, c->keys.p, total * sizeof(HostKeypoint), hipMemcpyDeviceToHost, cp.cs)) != hipSuccess)
+          fail("hipMemcpyAsync(keys)", e);
+        if (!rc && c->dim &&
+            (e = hipMemcpyAsync(hd->p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, cp.cs)) != hipSuccess)
+          fail("hipMemcpyAsync(desc)", e);
+        if (!rc && (e = hipStreamSynchronize(cp.cs)) != hipSuccess) fail("hipStreamSynchronize(copy stream)", e);
+      }
+    }
+    lk.lock();
+    cp.rc = rc;
+    cp.overflow = overflow;
+    cp.err = msg;
+    cp.has_job = false;
+    cp.done = true;
+    cp.cv.notify_all();
+  }
+}
+
+int copier_start(hess_ctx* c) {
+  Copier& cp = c->cp;
+  if (cp.started) return 0;
+  HIP_TRY(c, hipStreamCreateWithFlags(&cp.cs, hipStreamNonBlocking));
+  HIP_TRY(c, hipEventCreateWithFlags(&cp.ev_done, hipEventDisableTiming));
+  try {
+    cp.th = std::thread(copier_main, c);
+  } catch (...) {
+    set_err(c, "cannot start the copier thread");
+    return HESS_ERR_NOMEM;
+  }
+  cp.started = true;
+  return 0;
+}
+
+void copier_stop(hess_ctx* c) {
+  Copier& cp = c->cp;
+  if (cp.started) {
+    {
+      std::unique_lock<std::mutex> lk(cp.mu);
+      cp.cv.wait(lk, [&] { return cp.done; });
+      cp.stop = true;
+      cp.cv.notify_all();
+    }
+    cp.th.join();
+    cp.started = false;
+  }
+  if (cp.cs) { (void)hipStreamDestroy(cp.cs); cp.cs = nullptr; }
+  if (cp.ev_done) { (void)hipEventDestroy(cp.ev_done); cp.ev_done = nullptr; }
+}
+
+// How the results of a batch of `batch` images reach the host (see the kDeliver* comment): small batches through the
+// descriptor kernel's own stores (lowest latency), larger ones by the copier thread's DMA copy (no kernel waits for
+// PCIe).  HESS_DELIVERY overrides.
+void choose_delivery(hess_ctx* c, int batch) {
+  int d = c->delivery_pref >= 0 ? c->delivery_pref : (batch <= c->mirror_max_batch ? kDeliverMirror : kDeliverDma);
+  if (d == kDeliverMirror && !c->host_fits) d = kDeliverDma;  // the mirror needs the worst case pinned up front
+  if (d == kDeliverDma && copier_start(c) != 0) d = kDeliverBlit;
+  c->delivery = d;
+  c->host_direct = d == kDeliverMirror;
+}
+
+// Enqueue the whole path (the per-image counts reach the pinned count block by feature_scan_kernel's own stores);
+// returns without waiting.
 int submit_impl(hess_ctx* c, const PendingRun& r) {
   if (!c->user_keys.empty() && r.batch != 1) {
     set_err(c, "a keypoint list applies to a single image");
@@ -725,33 +868,48 @@ int submit_impl(hess_ctx* c, const PendingRun& r) {
   }
   int rc = plan(c, r.width, r.height, r.batch);
   if (rc) return rc;
-  int* hs = (int*)c->h_small.p;
+  choose_delivery(c, r.batch);
   HIP_TRY(c, hipGetLastError());
   rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
   if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
-  if (!c->host_direct) {  // (with host-direct delivery feature_scan_kernel has stored both into h_small itself)
-    HIP_TRY(c, hipMemcpyAsync(hs, c->img_base.p, (size_t)(r.batch + 1) * 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipMemcpyAsync(hs + r.batch + 1, c->overflow.p, 16, hipMemcpyDeviceToHost, c->st));
+  if (c->delivery == kDeliverDma) {
+    Copier& cp = c->cp;
+    HIP_TRY(c, hipEventRecord(cp.ev_done, c->st));
+    std::lock_guard<std::mutex> lk(cp.mu);
+    cp.batch = r.batch;
+    cp.done = false;
+    cp.has_job = true;
+    cp.cv.notify_all();
   }
   return 0;
 }
 
-// Wait for the submitted batch, grow storage and re-run if a list overflowed, then bring the
-// keypoints and descriptors of the whole batch to the host with one transfer each.
+// Wait for the submitted batch, grow storage and re-run if a list overflowed; with kDeliverBlit bring the
+// keypoints and descriptors of the whole batch to the host with one transfer each (the other modes have
+// delivered them by now).
 int wait_impl(hess_ctx* c, const PendingRun& r) {
   int rc;
   int* hs = (int*)c->h_small.p;
   const int batch = r.batch;
   for (int attempt = 0;; attempt++) {
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    if (c->delivery == kDeliverDma) {
+      Copier& cp = c->cp;
+      std::unique_lock<std::mutex> lk(cp.mu);
+      cp.cv.wait(lk, [&] { return cp.done; });
+      if (cp.rc) { c->err = cp.err; return cp.rc; }
+    } else {
+      HIP_TRY(c, hipStreamSynchronize(c->st));
+    }
     const int of_raw = hs[batch + 1], of_feat = hs[batch + 2];
     if (!of_raw && !of_feat) break;
     if (attempt >= 8) { set_err(c, "feature storage keeps overflowing"); return HESS_ERR_NOMEM; }
-    // grow-only reallocation, then run the batch again (reference: SetLevelFeatureNum grows on demand)
+    // grow-only reallocation, then run the batch again (reference: SetLevelFeatureNum grows on demand,
+    // PyramidCU.cpp:393-397)
     if (of_raw) c->cap_raw = of_raw + of_raw / 4;
     if (of_feat) c->cap_feat = of_feat + of_feat / 4;
     c->planned = false;
+    c->regrown++;
     if (c->p.verbose) fprintf(stderr, "hessgpu: feature storage grown (raw %d, features %d)\n", c->cap_raw, c->cap_feat);
     if ((rc = submit_impl(c, r))) return rc;
   }
@@ -766,7 +924,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
   const size_t total = c->offs[batch];
   if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
   if (c->dim && (rc = ensure(c, c->h_desc, (total ? total : 1) * c->dim * 4, true))) return rc;
-  if (total && !c->host_direct) {
+  if (total && c->delivery == kDeliverBlit) {
     HIP_TRY(c, hipMemcpyAsync(c->h_keys.p, c->keys.p, total * sizeof(HostKeypoint), hipMemcpyDeviceToHost, c->st));
     if (c->dim)
       HIP_TRY(c, hipMemcpyAsync(c->h_desc.p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, c->st));
@@ -790,6 +948,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
     c->offs[1] = (size_t)num;
     c->user_result = true;
     c->user_keys.clear();  // _existing_keypoints = 0 after RunSIFT (SiftPyramid.cpp:182-184)
+    c->user_levels.clear();  // the parity hook covers one keypoint-list run
     c->user_on_current = false;
   }
   // stage times from the events of the last enqueue (config.h:17-31 order)
@@ -830,9 +989,11 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   hess_ctx* c = new (std::nothrow) hess_ctx();
   if (!c) return nullptr;
   if (params) c->p = *params; else default_params(&c->p);
+  bool reserved_nonzero = false;
+  for (int r : c->p.reserved) reserved_nonzero = reserved_nonzero || r != 0;
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
       c->p.first_octave < -3 ||  // "can't upsample by more than 8", PyramidCU.cpp:131-132
-      c->p.detector != 0) {      // the product is the GPU_HESSIAN build; the DoG detector exists in the test oracle only
+      reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;
@@ -857,7 +1018,13 @@ hess_ctx* hess_create(int device, const hess_params* params) {
     hess_destroy(c);
     return nullptr;
   }
-  { const char* zc = getenv("HESS_HOST_DIRECT"); c->host_direct_allowed = !(zc && zc[0] == '0'); }
+  if (const char* d = getenv("HESS_DELIVERY")) {
+    if (!strcmp(d, "mirror")) c->delivery_pref = kDeliverMirror;
+    else if (!strcmp(d, "dma")) c->delivery_pref = kDeliverDma;
+    else if (!strcmp(d, "blit")) c->delivery_pref = kDeliverBlit;
+  }
+  if (const char* m = getenv("HESS_MIRROR_MAX_BATCH")) c->mirror_max_batch = atoi(m);
+  if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
   return c;
 }
 
@@ -865,6 +1032,7 @@ void hess_destroy(hess_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
+  copier_stop(c);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
                     &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
@@ -956,37 +1124,54 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
     // Pageable memory: copied into the pinned staging buffer in chunks, each chunk's transfer enqueued as soon as
     // it is staged, so the copy engine works while the next chunk is being copied.  Large inputs are staged by a
     // few helper threads (one core copies at about 17 GB/s, a third of what the link takes).
-    // 4 MB chunks; a small input (one image) is cut in four so that its transfer, too, overlaps its staging
+    // 4 MB chunks; a small input (one image) is cut in four so that its transfer, too, overlaps its staging.
+    // Chunks are claimed (0 -> 1) by whichever thread gets there first and marked done (2) under the mutex; the
+    // calling thread walks them in order, copies the ones nobody has claimed and otherwise sleeps on the
+    // condition variable until the claimer is done.  A helper that cannot be started is simply missing: the
+    // calling thread then copies its share (nothing thrown crosses the C ABI).
     const size_t chunk = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)256 << 10, ((bytes / 4 + 65535) >> 16) << 16));
     const int nchunk = (int)((bytes + chunk - 1) / chunk);
     const int nthreads = bytes >= ((size_t)16 << 20) ? 4 : (bytes >= ((size_t)8 << 20) ? 2 : 1);  // helpers only where they pay for their start
-    std::vector<std::atomic<int>> done(nchunk);
-    for (auto& d : done) d.store(0, std::memory_order_relaxed);
-    auto stage_chunks = [&](int first) {
+    std::atomic<int>* state = new (std::nothrow) std::atomic<int>[nchunk];
+    if (!state) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
+    for (int k = 0; k < nchunk; k++) state[k].store(0, std::memory_order_relaxed);
+    std::mutex mu;
+    std::condition_variable cv;
+    auto copy_chunk = [&](int k) {
+      const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
+      memcpy((char*)c->h_stage.p + off, (const char*)pixels + off, len);
+      { std::lock_guard<std::mutex> lk(mu); state[k].store(2, std::memory_order_release); }
+      cv.notify_all();
+    };
+    auto helper = [&](int first) {  // a helper prefers its own residue class, so the threads do not fight over chunks
       for (int k = first; k < nchunk; k += nthreads) {
-        const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
-        memcpy((char*)c->h_stage.p + off, (const char*)pixels + off, len);
-        done[k].store(1, std::memory_order_release);
+        int expect = 0;
+        if (state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) copy_chunk(k);
       }
     };
-    std::vector<std::thread> helpers;
-    for (int t = 1; t < nthreads; t++) helpers.emplace_back(stage_chunks, t);
+    std::thread helpers[3];
+    int nstarted = 0;
+    for (int t = 1; t < nthreads; t++) {
+      try { helpers[nstarted] = std::thread(helper, t); nstarted++; } catch (...) { /* no helper: this thread copies */ }
+    }
     hipError_t cerr = hipSuccess;
     for (int k = 0; k < nchunk; k++) {
-      if (k % nthreads == 0 && !done[k].load(std::memory_order_acquire)) {  // this thread's own share, in step with the transfers
-        const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
-        memcpy((char*)c->h_stage.p + off, (const char*)pixels + off, len);
-        done[k].store(1, std::memory_order_release);
+      int expect = 0;
+      if (state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) copy_chunk(k);
+      else if (state[k].load(std::memory_order_acquire) != 2) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return state[k].load(std::memory_order_acquire) == 2; });
       }
-      while (!done[k].load(std::memory_order_acquire)) std::this_thread::yield();
       const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
       if (cerr == hipSuccess)
         cerr = hipMemcpyAsync((char*)c->stage.p + off, (const char*)c->h_stage.p + off, len, hipMemcpyHostToDevice, c->st);
     }
-    for (auto& h : helpers) h.join();
+    for (int t = 0; t < nstarted; t++) helpers[t].join();
+    delete[] state;
     HIP_TRY(c, cerr);
   }
   HIP_TRY(c, hipEventRecord(c->ev_load[1], c->st));
+  c->last_input_bytes = bytes;
   if (!c->pend) c->pend = new PendingRun();
   *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, true};
   rc = submit_impl(c, *c->pend);
@@ -1000,6 +1185,15 @@ int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pi
   int rc = hess_submit_host(c, pixels, width, height, pitch, image_stride, batch, format, pixtype);
   if (rc) return rc;
   return hess_wait(c);
+}
+
+int hess_last_input(hess_ctx* c, void* out, size_t bytes) {
+  if (!c || !out) return HESS_ERR_ARG;
+  if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
+  if (!c->last_input_bytes || bytes > c->last_input_bytes) { set_err(c, "no host input of that size is retained"); return HESS_ERR_STATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(out, c->stage.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int hess_set_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
@@ -1092,6 +1286,8 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
   }
   return HESS_ERR_ARG;
 }
+
+int hess_debug_regrown(hess_ctx* c) { return c ? c->regrown : HESS_ERR_ARG; }
 
 int hess_debug_list(hess_ctx* c, int img, hess_rawkey* out, int cap) {
   if (!c || !c->d_list || img < 0 || img >= c->batch) return HESS_ERR_ARG;

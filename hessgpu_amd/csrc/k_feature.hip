@@ -9,9 +9,10 @@
 // One 64-lane wavefront per keypoint (orientation) / per feature (descriptor); every histogram bin
 // receives its contributions in the reference's sample order (row-major over the window), so sums are
 // bit-identical to a sequential scan.
-//   orientation  64 window samples per step, one per lane, branch-free; the samples inside the disc are
-//                compacted in order into an LDS record list; lane j (bin j) reads every record by LDS
-//                broadcast and adds it with coefficient (bin == j ? gradient : 0);
+//   orientation  64 window samples per step, one per lane, branch-free; the samples inside the disc are grouped
+//                by bin (rank inside the group from ballots of the bin bits, groups placed back to back in an
+//                LDS list by a DPP scan of the group sizes), each group in lane order = the reference's sample
+//                order; lane j (bin j) reads and adds only its own group;
 //   descriptor   lane = cell*4 + q: the four lanes of a cell take four consecutive samples of the cell's
 //                box per iteration (the reference's scan order); lane (cell, q) owns bins q, q+4 (q = 0 also 8)
 //                of its cell and adds the iteration's samples to them through a per-wavefront LDS coefficient
@@ -165,12 +166,18 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
         const int myrank = __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u));
         // group sizes reach the bin owners through LDS: the last sample of a group knows its size
         const int gsize = __popc(same_lo) + __popc(same_hi);
+        // (cross-lane exchanges through LDS inside one wavefront: DS operations of a wavefront execute in order; the
+        // wave barriers only pin the compiler's ordering of the may-alias accesses, they emit no instruction)
         if (lane < 36) mysize[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
         if (counted & (myrank + 1 == gsize)) mysize[bin] = gsize;
+        __builtin_amdgcn_wave_barrier();
         const int mycnt = (lane < 36) ? mysize[lane] : 0;
         const int mystart = wave_inclusive_scan(mycnt) - mycnt;
         const int pos = __shfl(mystart, counted ? bin : 0) + myrank;
+        __builtin_amdgcn_wave_barrier();  // the previous step's group reads precede this step's record stores
         if (counted) myrec[pos] = make_float2(gv.x, e);
+        __builtin_amdgcn_wave_barrier();
         for (int k = 0; __builtin_amdgcn_ballot_w64(k < mycnt) != 0; k += 2) {
           if (k < mycnt) {  // two records per trip (a group's records are adjacent; the list has a spare slot)
             const float2 r0 = myrec[mystart + k], r1 = myrec[mystart + k + 1];  // one ds_read2_b64
@@ -643,12 +650,15 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         const int fidx = min(max((int)fo, 0), DC_BINS - 2);  // 0..8 for every finite theta; never outside the table
         mycol[fidx * DC_BIN_PITCH] = w1;
         mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = w2;
+        __builtin_amdgcn_wave_barrier();  // cross-lane through LDS inside the wavefront: pins the compiler's order only
         const float4 c0 = *reinterpret_cast<const float4*>(rdbin);
         const float4 c1 = *reinterpret_cast<const float4*>(rdbin + 4 * DC_BIN_PITCH);
         const float4 c2 = *reinterpret_cast<const float4*>(rdbin + 8 * DC_BIN_PITCH);
+        __builtin_amdgcn_wave_barrier();
         accumulate(c0, c1, c2, wt);
         mycol[fidx * DC_BIN_PITCH] = 0.0f;
         mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
       };
 #pragma unroll
       for (int u = 0; u < N; u++) {
@@ -686,6 +696,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
       dl[wv][mycell * 8 + 4 + sub] = acc1;
     }
     // same wavefront wrote dl[wv]; LDS operations of one wavefront complete in order
+    __builtin_amdgcn_wave_barrier();
     float* dout = desc + (obase + oidx) * dim;
     if (dp.half_sift) {
       float2 v = make_float2(0, 0);

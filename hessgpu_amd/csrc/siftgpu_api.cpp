@@ -42,12 +42,19 @@ struct Impl {
   int tight = 0;
   float mr_size = 3.0f;       // GlobalUtil.cpp:93
   std::vector<std::string> list;
-  // current image (a copy: the reference borrows the caller's pointer only during the call)
+  // current image.  RunSIFT(w,h,data,..) borrows the caller's pointer for the call, as the reference does; the copy
+  // the reference keeps for a later RunSIFT() (GLTexInput::_pixel_data) stays in the context's staging area and is
+  // only brought back (hess_last_input) if the image is in fact run again without being handed over again.
   std::vector<unsigned char> pixels;
+  const void* borrowed = nullptr;   // caller's pixels, during RunSIFT(w,h,data,..) only
+  bool pixels_in_ctx = false;       // `pixels` is stale: the current image's pixels are the context's last input
   int w = 0, h = 0, fmt = 0, pix = 0;
-  // results of the last run
+  // results of the last run: they stay in the context's pinned host buffers (GetFeatureVector copies from there
+  // straight into the caller's arrays) and are only copied here when something else needs them (SaveSIFT, or the
+  // context being rebuilt after a parameter change)
   std::vector<hess_keypoint> keys;
   std::vector<float> desc;
+  bool results_in_ctx = false;
   int nfeat = 0, dim = 0;
   std::vector<hess_keypoint> pending_keys;  // SetKeypointList before the context existed / was rebuilt
   int pending_keys_orient = 1;
@@ -178,16 +185,37 @@ namespace {
 struct Peek0 : SiftGPU {
   static Impl* impl(SiftGPU* s) { return I(static_cast<Peek0*>(s)->_pyramid); }
 };
-// Copy counts, keypoints, descriptors and stage times of the last run out of the context.
+// Counts and stage times of the last run; the keypoints and descriptors stay in the context (see Impl).
 void collect_results(SiftGPU* self) {
   Impl* im = Peek0::impl(self);
   im->nfeat = hess_count(im->ctx, 0);
   im->dim = hess_desc_dim(im->ctx);
+  im->results_in_ctx = true;
+  const float* t = hess_timing(im->ctx);
+  for (int k = 0; k < 12; k++) self->_timing[k] = t[k];
+}
+// Bring the results of the last run into the instance's own arrays (before the context goes away, or for SaveSIFT).
+void materialize_results(Impl* im) {
+  if (!im->results_in_ctx || !im->ctx) return;
   im->keys.resize(im->nfeat ? im->nfeat : 1);
   im->desc.resize((size_t)(im->nfeat ? im->nfeat : 1) * (im->dim ? im->dim : 1));
   hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
-  const float* t = hess_timing(im->ctx);
-  for (int k = 0; k < 12; k++) self->_timing[k] = t[k];
+  im->results_in_ctx = false;
+}
+// Same for the pixels of the current image.
+bool materialize_pixels(Impl* im) {
+  if (!im->pixels_in_ctx) return true;
+  const size_t bytes = (size_t)im->w * im->h * channels(im->fmt) * pix_bytes(im->pix);
+  im->pixels.resize(bytes);
+  im->pixels_in_ctx = false;
+  return im->ctx && hess_last_input(im->ctx, im->pixels.data(), bytes) == 0;
+}
+void drop_context(Impl* im) {
+  if (!im->ctx) return;
+  materialize_results(im);
+  materialize_pixels(im);
+  hess_destroy(im->ctx);
+  im->ctx = nullptr;
 }
 }  // namespace
 
@@ -392,7 +420,7 @@ void SiftGPU::InitSiftGPU() {
   p.dog_threshold = _dog_threshold;
   p.edge_threshold = _edge_threshold;
   p.verbose = im->verbose;
-  if (im->ctx) { hess_destroy(im->ctx); im->ctx = nullptr; }
+  drop_context(im);  // (results and pixels of the last run are kept in the instance)
   im->ctx = hess_create(im->device, &p);
   im->p = p;
   im->dirty = false;
@@ -443,12 +471,16 @@ int SiftGPU::RunSIFT(int width, int height, const void* data, unsigned int gl_fo
     std::cerr << "Input format not supported under current settings.\n";
     return 0;
   }
-  const size_t bytes = (size_t)width * height * channels(fmt) * pix_bytes(pix);
-  im->pixels.assign((const unsigned char*)data, (const unsigned char*)data + bytes);
   im->w = width; im->h = height; im->fmt = fmt; im->pix = pix;
   _imgpath[0] = 0;
   _image_loaded = 2;
-  return RunSIFT();
+  im->borrowed = data;  // no copy here: the context stages the pixels and keeps them until the next image
+  im->pixels_in_ctx = false;
+  const int ok = RunSIFT();
+  im->borrowed = nullptr;
+  im->pixels_in_ctx = ok != 0;
+  if (!ok) { _image_loaded = 0; im->pixels.clear(); }
+  return ok;
 }
 
 int SiftGPU::RunSIFT(int num, const SiftKeypoint* keys, int keys_have_orientation) {  // SiftGPU.cpp:307-315
@@ -484,13 +516,19 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
     }
     im->fmt = HESS_FMT_LUM;
     im->pix = HESS_PIX_U8;
+    im->pixels_in_ctx = false;
     if (im->verbose) std::cout << "Image loaded :\t" << _imgpath << "\n";
   }
   _image_loaded = 1;
   if (!im->pending_keys.empty())
     hess_set_keypoints(im->ctx, im->pending_keys.data(), (int)im->pending_keys.size(), im->pending_keys_orient);
   const int pitch = im->w * channels(im->fmt) * pix_bytes(im->pix);
-  const int rc = hess_run_host(im->ctx, im->pixels.data(), im->w, im->h, pitch, (size_t)pitch * im->h, 1, im->fmt, im->pix);
+  const void* px = im->borrowed;
+  if (!px) {  // RunSIFT() on the current image again: its pixels may still be with the context only
+    if (!materialize_pixels(im)) { std::cerr << "SiftGPU: the current image's pixels are gone\n"; return 0; }
+    px = im->pixels.data();
+  }
+  const int rc = hess_run_host(im->ctx, px, im->w, im->h, pitch, (size_t)pitch * im->h, 1, im->fmt, im->pix);
   if (rc != 0) {
     std::cerr << "SiftGPU: " << hess_last_error(im->ctx) << "\n";
     im->nfeat = 0;
@@ -512,6 +550,10 @@ int SiftGPU::GetFeatureNum() { return I(_pyramid)->nfeat; }
 void SiftGPU::GetFeatureVector(SiftKeypoint* keys, float* descriptors) {  // SiftPyramid.cpp:313-324
   Impl* im = I(_pyramid);
   static_assert(sizeof(SiftKeypoint) == sizeof(hess_keypoint), "keypoint layout");
+  if (im->results_in_ctx && im->ctx) {  // straight from the context's pinned result buffers into the caller's arrays
+    if (im->nfeat) hess_fetch(im->ctx, 0, reinterpret_cast<hess_keypoint*>(keys), im->dim ? descriptors : nullptr);
+    return;
+  }
   if (keys && im->nfeat) memcpy(keys, im->keys.data(), (size_t)im->nfeat * sizeof(SiftKeypoint));
   // The reference always copies 128*n floats, over-reading its 64*n buffer in -half mode; here dim*n.
   if (descriptors && im->dim && im->nfeat) memcpy(descriptors, im->desc.data(), (size_t)im->nfeat * im->dim * sizeof(float));
@@ -520,6 +562,7 @@ void SiftGPU::GetFeatureVector(SiftKeypoint* keys, float* descriptors) {  // Sif
 void SiftGPU::SaveSIFT(const char* szFileName) {  // SiftPyramid::SaveSIFT, SiftPyramid.cpp:357-571
   Impl* im = I(_pyramid);
   if (im->nfeat <= 0) return;
+  materialize_results(im);
   const int n = im->nfeat, dim = im->dim;
   const hess_keypoint* pk = im->keys.data();
   const float* pd = im->desc.data();

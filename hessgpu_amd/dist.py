@@ -64,6 +64,8 @@ def _exchange_counts(counts, dev, world, group):
 def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     """Gather per-image feature lists to rank `dst`, every rank sending exactly its own records.
 
+    dst       destination rank INSIDE `group` (group-local numbering; with group=None that is the global rank).
+              Use dist.get_group_rank(group, global_rank) to convert a global rank.
     counts    list[int], features per local image (same number of local images on every rank)
     keys_u8   uint8 tensor [sum(counts), 24]  (hess_keypoint records, local images back to back)
     desc_f32  float32 tensor [sum(counts), dim] or None when descriptors are off
@@ -140,3 +142,71 @@ def host_feature_tensors(session, counts):
     dim = session.desc_dim()
     desc = torch.from_numpy(np.concatenate(ds).copy()) if dim else None
     return keys, desc
+
+
+class HostLanding:
+    """Pinned host buffers on the destination rank for the gathered lists of the OTHER ranks, so that a multi-rank
+    step ends where a single-rank step ends: with every feature list of the global batch in host memory (the
+    destination's own block is already there, delivered by its context).
+
+    The copy is issued on a stream of its own after the host has waited for the receives, i.e. with no stream-order
+    dependency on a kernel: the runtime then uses the DMA engine instead of a blit kernel (hess_pipeline.hip,
+    kDeliverDma, for the same reason).  Buffers grow on demand and are reused from step to step."""
+
+    def __init__(self):
+        self._keys = None
+        self._desc = None
+        self._stream = None
+        self.keys = []   # per source rank: uint8 [n_r, 24] host views (None for the destination's own block)
+        self.desc = []
+
+    @staticmethod
+    def _buffer(old, nbytes, pin):
+        if old is not None and old.numel() >= nbytes:
+            return old
+        t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8)
+        return t.pin_memory() if pin else t
+
+    def land(self, keys_list, desc_list, own_rank):
+        """keys_list / desc_list as returned by gather_feature_lists on the destination rank."""
+        on_gpu = any(k.is_cuda for k in keys_list)
+        dim = desc_list[0].shape[1] if desc_list is not None else 0
+        nk = sum(k.shape[0] for r, k in enumerate(keys_list) if r != own_rank)
+        self._keys = self._buffer(self._keys, nk * KEY_BYTES, on_gpu)
+        if dim:
+            self._desc = self._buffer(self._desc, nk * dim * 4, on_gpu)
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()      # the receives are done: nothing below follows a kernel
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+        self.keys, self.desc = [], []
+        at = 0
+        ctx = torch.cuda.stream(self._stream) if on_gpu else _NullContext()
+        with ctx:
+            for r, k in enumerate(keys_list):
+                if r == own_rank:
+                    self.keys.append(None)
+                    self.desc.append(None)
+                    continue
+                n = k.shape[0]
+                hk = self._keys[at * KEY_BYTES:(at + n) * KEY_BYTES].view(n, KEY_BYTES)
+                hk.copy_(k, non_blocking=on_gpu)
+                self.keys.append(hk)
+                if dim:
+                    hd = self._desc[at * dim * 4:(at + n) * dim * 4].view(torch.float32).view(n, dim)
+                    hd.copy_(desc_list[r], non_blocking=on_gpu)
+                    self.desc.append(hd)
+                else:
+                    self.desc.append(None)
+                at += n
+        if on_gpu:
+            self._stream.synchronize()
+        return self.keys, self.desc
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

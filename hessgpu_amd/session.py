@@ -191,6 +191,10 @@ class Session:
         self._check(self._f["device_results"](self._h, C.byref(k), C.byref(d), C.byref(cap)))
         return k.value, d.value, cap.value
 
+    def regrown(self):
+        """Times the context grew its feature storage after an overflow and ran the batch again (product only)."""
+        return self._check(self._f["debug_regrown"](self._h))
+
     # -- profiling (product only) --------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._f["profile_enable"](self._h, int(on)))

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define HESS_ABI_VERSION 1
+/* 2: hess_params.reserved[] must be zero (the oracle-only `detector` word of version 1 is gone from the product's
+ *    struct); hess_submit_host, hess_device_count, hess_debug_key_levels (now covering one run), hess_debug_regrown. */
+#define HESS_ABI_VERSION 2
 
 typedef enum hess_status {
   HESS_OK = 0,
@@ -88,12 +90,8 @@ typedef struct hess_params {
   int32_t dynamic_indexing;     /* -di  descriptor bins indexed dynamically (GlobalUtil.cpp:108,
                                    ProgramCU.cu:1755-1771): a sample whose bin coordinate rounds up to
                                    exactly 8.0 is then added to bin 8 (folded into bin 0), not dropped */
-  int32_t detector;             /* 0 = determinant of Hessian (GPU_HESSIAN, the only detector of the product:
-                                   hess_create refuses anything else).  1 = difference of Gaussians as the
-                                   reference compiles without GPU_HESSIAN (config.h:36): accepted by the CPU oracle
-                                   only, to reproduce the reference's doc/evaluation/box.siftgpu from pixels;
-                                   2 = the same with the level sigmas of the version that wrote that file */
-  int32_t reserved[6];
+  int32_t reserved[7];          /* must be zero: hess_create refuses anything else (word 0 is where the test
+                                   oracle keeps its detector switch, oracle/hess_oracle.h -- not a product option) */
 } hess_params;
 
 /* Binary-identical to SiftGPU::SiftKeypoint (SiftGPU.h:108-116): 24 bytes. */
@@ -164,6 +162,13 @@ int hess_wait(hess_ctx* ctx);
 int hess_run_device(hess_ctx* ctx, const void* dev_pixels, int width, int height, int pitch,
                     size_t image_stride, int batch, int format, int pixtype);
 
+/* The pixels of the last batch handed over with hess_submit_host / hess_run_host, as they were handed over (the
+ * context keeps them in its staging area until the next batch).  Replaces GLTexInput keeping the converted image in
+ * _pixel_data between calls (GLTexImage.cpp:918-1036, PyramidCU.cpp:1458-1462), which is what lets the reference's
+ * SiftGPU::RunSIFT() run the current image again: this build's SiftGPU class borrows the caller's pointer for the call
+ * and only comes back for the pixels if the image is run again without being handed over again. */
+int hess_last_input(hess_ctx* ctx, void* out, size_t bytes);
+
 /* Replaces SiftGPU::SetKeypointList -> SiftPyramid::SetKeypointList (SiftPyramid.cpp:326-355): the
  * NEXT hess_run_* call (one image) skips detection and computes orientation (unless
  * keys_have_orientation) and descriptors for these keypoints (PyramidCU::GenerateFeatureListTex,
@@ -195,8 +200,13 @@ int hess_geometry(hess_ctx* ctx, int* widths, int* heights);
 int hess_debug_level(hess_ctx* ctx, int img, int octave, int level, int what, float* out);
 /* Parity hook for the reference's feature file (tests/test_reference_fixture.py): describe user keypoint k
  * at level index levels[k] = octave*dog_level_num + (level-1) instead of the level the scale rule of
- * GenerateFeatureListTex picks (-1 keeps the rule; NULL/0 clears).  Applies to later set/run_keypoints. */
+ * GenerateFeatureListTex picks (-1 keeps the rule; NULL/0 clears).  Applies to the NEXT keypoint-list run only
+ * (hess_set_keypoints + hess_run_*, or hess_run_keypoints) and is cleared by it. */
 int hess_debug_key_levels(hess_ctx* ctx, const int* levels, int num);
+/* Robustness hook: how many times this context has grown its feature storage after an overflow and run a batch
+ * again (the reference grows its lists per image, PyramidCU.cpp:393-397).  The environment variable
+ * HESS_INITIAL_CAP=<n> makes a new context start with room for n detections per image so that tests can force it. */
+int hess_debug_regrown(hess_ctx* ctx);
 /* Raw detections of image `img` in list order; returns the count (<= cap written). */
 int hess_debug_list(hess_ctx* ctx, int img, hess_rawkey* out, int cap);
 

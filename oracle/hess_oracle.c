@@ -126,7 +126,7 @@ static void resolve_params(hess_cpu_ctx* c) {
   if (p->max_orientation < 1) p->max_orientation = 1; /* SiftGPU.cpp:1047 clamps to 1..4 */
   if (p->max_orientation > 4) p->max_orientation = 4;
   float sigmak = powf(2.0f, 1.0f / p->dog_level_num);
-  if (p->detector == 0) {
+  if (HESS_ORACLE_DETECTOR(p) == 0) {
     c->level_max = p->dog_level_num + 1;
     c->level_num = c->level_max + 1;
     c->level_ds = p->dog_level_num; /* _level_min + _dog_level_num, <= _level_max */
@@ -149,7 +149,7 @@ static void resolve_params(hess_cpu_ctx* c) {
       c->sigma[i] = dsigma0 * powf(sigmak, (float)i);
     for (int l = 0; l <= c->level_max; l++) /* GetLevelSigma(level = l - 1), :1422-1425 */
       c->level_sigma[l] = sigma0 * powf(2.0f, (float)(l - 1) / (float)p->dog_level_num);
-    if (p->detector == 2) {
+    if (HESS_ORACLE_DETECTOR(p) == 2) {
       /* The keypoint scales of doc/evaluation/box.siftgpu are sigma0 * 2^(level / (2 dog)) * step^ds: the file was
        * written before the "bug fix 9/12/2007" that GetLevelSigma's comment records (measured on the file: the
        * ratio to today's formula is 2^(level/6) to four digits at each of the three levels).  Only the sigma handed
@@ -168,7 +168,7 @@ static void resolve_params(hess_cpu_ctx* c) {
 /* SiftParam::GetInitialSmoothSigma, SiftGPU.cpp:482-489 (_level_min = 0). */
 static float initial_smooth_sigma(const hess_cpu_ctx* c, int octave_min) {
   /* sa = _sigma0 * 2^(_level_min / dog): level_min = 0 (Hessian) or _sigma0 = 1.6 * 2^(1/dog), level_min = -1 (DoG) */
-  float sa = c->p.detector == 0
+  float sa = HESS_ORACLE_DETECTOR(&c->p) == 0
                  ? c->p.sigma0 * powf(2.0f, 0.0f / (float)c->p.dog_level_num)
                  : (c->p.sigma0 * powf(2.0f, 1.0f / c->p.dog_level_num)) * powf(2.0f, -1.0f / (float)c->p.dog_level_num);
   float sb = c->p.sigman / powf(2.0f, (float)octave_min);
@@ -561,7 +561,7 @@ static void compute_orientation(const hess_cpu_ctx* c, const hess_rawkey* rk, co
       float off = 0.5f * ((next - pre) / (weight + weight - next - pre));
       kw = radius_per_ten_degrees * (index_max + 0.5f + off);
       kw_bits = om_f2u(kw);
-    } else if (p->detector != 0) {
+    } else if (HESS_ORACLE_DETECTOR(p) != 0) {
       /* build without GPU_HESSIAN, ProgramCU.cu:1493-1548: the two strongest peaks, 16-bit angles, 65535 = none */
       float max_vote = vote[0];
       for (int i = 1; i < 36; ++i) max_vote = fmaxf(max_vote, vote[i]);
@@ -827,7 +827,7 @@ hess_cpu_ctx* hess_cpu_create(const hess_params* params) {
   if (params) c->p = *params; else hess_cpu_default_params(&c->p);
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > 10 ||
       c->p.first_octave < -3 || /* "can't upsample by more than 8", PyramidCU.cpp:131-132 */
-      c->p.detector < 0 || c->p.detector > 2) {
+      HESS_ORACLE_DETECTOR(&c->p) < 0 || HESS_ORACLE_DETECTOR(&c->p) > 2) {
     free(c);
     return NULL;
   }
@@ -1121,7 +1121,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     for (int l = 0; l <= c->level_max; l++) {
       float ls = c->level_sigma[l] * 1.0f; /* octaveSigma = 1, PyramidCU.cpp:1574-1585 */
       compute_hessian(py->gauss[o][l], py->deth[o][l], py->got[o][l], c->g[o].wa, c->g[o].h, ls * ls);
-      if (p->detector != 0 && l >= 1) { /* ComputeDOG_Kernel, ProgramCU.cu:598-637: the plane the extrema are sought in */
+      if (HESS_ORACLE_DETECTOR(p) != 0 && l >= 1) { /* ComputeDOG_Kernel, ProgramCU.cu:598-637: the plane the extrema are sought in */
         const float* a = py->gauss[o][l];
         const float* b = py->gauss[o][l - 1];
         float* d = py->deth[o][l];
@@ -1150,7 +1150,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     keyval kv;
     /* without GPU_HESSIAN the list `level` (0..dog-1) is sought in DoG plane level + 2 of that build = l + 1 here
      * (between Gaussian levels l and l + 1) and described from Gaussian level l (PyramidCU.cpp:1655-1670, 1825-1846) */
-    const int dm = p->detector != 0, pl = dm ? l + 1 : l;
+    const int dm = HESS_ORACLE_DETECTOR(p) != 0, pl = dm ? l + 1 : l;
     for (int row = 1; row < h - 1; row++)
       for (int col = 1; col < wa - 1; col++)
         if (compute_key(py->deth[o][pl], py->deth[o][pl - 1], py->deth[o][pl + 1], py->gauss[o][l], wa, row, col,
@@ -1256,7 +1256,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   if (!frecs || !angles || !flevel || !keys) return HESS_ERR_NOMEM;
   {
     const double twopi = 2.0 * PI_D;
-    const double factor = p->detector != 0 ? 2.0 * PI_D / 65535.0 : 2.0 * PI_D / 255.0; /* PyramidCU.cpp:763-767 */
+    const double factor = HESS_ORACLE_DETECTOR(p) != 0 ? 2.0 * PI_D / 65535.0 : 2.0 * PI_D / 255.0; /* PyramidCU.cpp:763-767 */
     float octave_sigma = first_octave_sigma(c); /* 2^_octave_min */
     float offset = p->lowe_origin ? 0.0f : 0.5f;
     int m = 0;
@@ -1267,7 +1267,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
         frecs[m] = recs[n];
         flevel[m] = li;
         angles[m] = !multi ? om_u2f(recs[n].w)
-                    : (p->detector != 0 ? (float)(factor * ((recs[n].w >> (16 * k)) & 0xFFFFu))
+                    : (HESS_ORACLE_DETECTOR(p) != 0 ? (float)(factor * ((recs[n].w >> (16 * k)) & 0xFFFFu))
                                         : (float)(factor * ((recs[n].w >> (8 * k)) & 0xFFu)));
         float oss = octave_sigma * (float)(1 << (li / dog));
         float posX = FIXED_TO_FLOAT(recs[n].x & 0x00FFFFFFu, 10);
@@ -1356,6 +1356,7 @@ int hess_cpu_run_host(hess_cpu_ctx* c, const void* pixels, int width, int height
     if (rc) { snprintf(c->err, sizeof(c->err), "image %d failed (%d)", b, rc); return rc; }
   }
   c->timing[HESS_T_TOTAL] = (float)(now_ms() - t0);
+  if (c->user_num > 0) hess_cpu_debug_key_levels(c, NULL, 0); /* the hook covers one keypoint-list run */
   hess_cpu_set_keypoints(c, NULL, 0, 0); /* _existing_keypoints = 0 after RunSIFT, SiftPyramid.cpp:182-184 */
   return 0;
 }
@@ -1385,6 +1386,7 @@ int hess_cpu_run_keypoints(hess_cpu_ctx* c, const hess_keypoint* keys, int num, 
   free(R->keys); free(R->desc);
   R->keys = NULL; R->desc = NULL;
   rc = user_keypoint_path(c, R);
+  hess_cpu_debug_key_levels(c, NULL, 0); /* the hook covers one keypoint-list run */
   hess_cpu_set_keypoints(c, NULL, 0, 0);
   return rc;
 }

@@ -35,6 +35,13 @@ extern "C" {
 
 typedef struct hess_cpu_ctx hess_cpu_ctx;
 
+/* The oracle's one extension of hess_params: which detector it runs.  It lives in reserved word 0, which the
+ * product requires to be zero (hess_create refuses the struct otherwise), so it is not an option of the product.
+ *   0 = determinant of Hessian (GPU_HESSIAN: what the product computes)
+ *   1 = difference of Gaussians as the reference compiles without GPU_HESSIAN (config.h:36)
+ *   2 = the same with the level sigmas of the version that wrote doc/evaluation/box.siftgpu */
+#define HESS_ORACLE_DETECTOR(p) ((p)->reserved[0])
+
 void hess_cpu_default_params(hess_params* p);
 hess_cpu_ctx* hess_cpu_create(const hess_params* params);
 void hess_cpu_destroy(hess_cpu_ctx* ctx);

@@ -107,11 +107,12 @@ def analyse(session, img, vals):
     errs, angs, descs, levels = [], [], [], []
     for off in (0, 1, 2):
         lv = np.clip(np.floor(t).astype(np.int64) + off, 0, nlev - 1).astype(np.int32)
-        session.debug_key_levels(lv)
+        session.debug_key_levels(lv)                            # (the hook covers one run: set again below)
         assert session.run_keypoints(keys, True) == n           # descriptors from the file's orientation
         d = session.fetch(0)[1]
         errs.append(np.abs(np.floor(512.0 * d + 0.5) - vals[:, 4:]).max(axis=1))   # SaveSIFT, SiftPyramid.cpp:504-566
         descs.append(d)
+        session.debug_key_levels(lv)
         assert session.run_keypoints(keys, False) == n          # ComputeOrientation, strongest only (ProgramCU.cu:1398-1420)
         angs.append(session.fetch(0)[0]["o"].astype(np.float64))
         levels.append(lv)

@@ -51,7 +51,9 @@ def lib():
 class OracleSession(Session):
     def __init__(self, threads=1, keep_levels=True, **overrides):
         l = lib()
+        detector = overrides.pop("detector", 0)   # the oracle's extension word (oracle/hess_oracle.h), not a product option
         p = make_params(_fns["default_params"], **overrides)
+        p.reserved[0] = detector
         h = l.hess_cpu_create(C.byref(p))
         super().__init__(_fns, h, p)
         l.hess_cpu_set_threads(h, threads)

@@ -12,28 +12,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--batch", "2"], capture_output=True, text=True, timeout=600)
+                        "--batch", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_secondary", "cpu_baseline",
-              "value_host_to_host", "latency_ms_single_image", "parity_checked", "kernel_ms_per_step"):
+              "value_host_to_host", "value_device_resident", "latency_ms_single_image", "parity_checked",
+              "kernel_ms_per_step", "value_siftgpu_api_1thread", "value_siftgpu_api_threads", "configs4"):
         assert k in d, k
     assert d["unit"] == "Mpix/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
-    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 1920 * 1080 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
+    assert d["value"] > 0 and abs(d["value"] - 3 * 3 * 1920 * 1080 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
+    assert d["value_device_resident"] == d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
     kernels = {rf["kernel"].split()[0], d["roofline_secondary"]["kernel"].split()[0]}
-    assert kernels == {"gauss_kernel", "descriptor_kernel<true>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
+    # a batch of three images is delivered by the copier thread: the descriptor launch does not mirror to the host
+    assert kernels == {"gauss_kernel", "descriptor_kernel<false>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
     dk = rf if rf["kernel"].startswith("descriptor") else d["roofline_secondary"]
-    assert dk["without_host_mirror"]["kernel"] == "descriptor_kernel<false>" and dk["without_host_mirror"]["avg_launch_us"] > 0
+    assert dk["with_host_mirror"]["kernel"] == "descriptor_kernel<true>" and dk["with_host_mirror"]["avg_launch_us"] > 0
+    assert dk["valu"]["peak"] == 1228.8 and 0 < dk["valu"]["frac"] < 1
     assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
     assert 0 < d["value_host_to_host"] and 0 < d["latency_ms_single_image"] < 100
-    assert d["config"]["distinct_images_per_gpu"] == 2 and "configs[1]" in d["config"]["workload"]
+    assert d["config"]["distinct_images_per_gpu"] == 3 and "configs[1]" in d["config"]["workload"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mpix/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # the plugin surface (libsiftgpu.so: RunSIFT(w,h,data) + GetFeatureVector), one and several instances
+    assert d["value_siftgpu_api_1thread"] > 0 and d["value_siftgpu_api_threads"] > 0
+    c4 = d["configs4"]
+    assert "configs[4]" in c4["workload"] and c4["features"] >= 65536
+    assert c4["Mpix_per_s_one_context"] > 0 and c4["Mpix_per_s_three_contexts"] > 0
+    r4 = c4["roofline_descriptor"]
+    assert r4["bound"] == "hbm" and r4["peak"] == 8000.0 and 0 < r4["frac"] < 1 and r4["features_per_launch"] == c4["features"]

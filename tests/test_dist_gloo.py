@@ -53,8 +53,18 @@ def _worker(rank, world, port, n_images, result_path):
         all_counts, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0)
         if rank == 0:
             flat_counts = [c for r in all_counts for c in r]
+            # the other ranks' lists landed in the destination's host buffers (bench.py --gather-dest host): the
+            # destination's own block stays where its context delivered it; buffers are reused from step to step
+            landing = hdist.HostLanding()
+            for _ in range(2):
+                hk, hd = landing.land(gk, gd, own_rank=0)
+            assert hk[0] is None and hd[0] is None
+            for r in range(1, world):
+                assert torch.equal(hk[r], gk[r]) and torch.equal(hd[r], gd[r]) and hk[r].data_ptr() != gk[r].data_ptr()
+            lk = [gk[0]] + [hk[r] for r in range(1, world)]
+            ld = [gd[0]] + [hd[r] for r in range(1, world)]
             np.savez(result_path, counts=np.array(flat_counts),
-                     keys=np.concatenate([k.numpy() for k in gk]), desc=np.concatenate([d.numpy() for d in gd]))
+                     keys=np.concatenate([k.numpy() for k in lk]), desc=np.concatenate([d.numpy() for d in ld]))
         else:
             assert gk is None and gd is None
     finally:
@@ -108,5 +118,37 @@ def _ragged_worker(rank, world, port, result_path):
         if rank == 0:
             np.savez(result_path, counts=np.array([c for r in all_counts for c in r]), sizes=np.array([len(k) for k in gk]),
                      keys=np.concatenate([k.numpy() for k in gk]), desc=np.concatenate([d.numpy() for d in gd]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_inside_a_subgroup_uses_group_local_ranks(tmp_path):
+    """`dst` of gather_feature_lists is a rank INSIDE the group: with the sub-group (1, 2) of a 3-rank job,
+    dst=1 is global rank 2 (global rank 1 is nobody's destination)."""
+    out = str(tmp_path / "g3.npz")
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out)
+    assert got["dst_global"] == 2 and got["counts"].tolist() == [2, 4]          # group order: global 1, then global 2
+    assert got["keys"][:, 0].tolist() == [1, 1, 2, 2, 2, 2]
+
+
+def _subgroup_worker(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group(ranks=[1, 2])          # every rank takes part in creating it
+        if rank in (1, 2):
+            n = {1: 2, 2: 4}[rank]
+            keys = torch.full((n, 24), rank, dtype=torch.uint8)
+            desc = torch.full((n, 128), float(rank), dtype=torch.float32)
+            all_counts, gk, gd = hdist.gather_feature_lists([n], keys, desc, dst=1, group=grp)
+            if dist.get_rank(grp) == 1:
+                np.savez(result_path, dst_global=rank, counts=np.array([c for r in all_counts for c in r]),
+                         keys=np.concatenate([k.numpy() for k in gk]))
+            else:
+                assert gk is None
+        dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -237,18 +237,102 @@ def test_parity_noise_ragged(gpu_ctx_factory, w, h):
     _compare_all(g, o, img, f"noise {w}x{h}")
 
 
-def test_result_delivery_by_copy(gpu_ctx_factory, monkeypatch):
-    """Results normally reach the host through stores of the descriptor kernel into pinned memory; when the
-    worst-case result size is too large for that (or HESS_HOST_DIRECT=0) a device->host copy follows the
-    kernels instead.  Same results either way."""
-    monkeypatch.setenv("HESS_HOST_DIRECT", "0")
-    imgs = np.stack([fixtures.load_rgb(n) for n in fixtures.list640()[:3]])
+@pytest.mark.parametrize("mode", ["mirror", "dma", "blit"])
+def test_result_delivery_modes(gpu_ctx_factory, monkeypatch, mode):
+    """Three ways for the results to reach the host (hess_pipeline.hip, kDeliver*): stores of the descriptor kernel
+    into pinned memory (small batches), a DMA copy issued by the context's copier thread once the kernels are done
+    (larger batches), and a device->host copy on the context's stream after hess_wait has read the counts (the
+    fallback).  Same results every way, for one image and for a batch, also when modes alternate on one context."""
+    monkeypatch.setenv("HESS_DELIVERY", mode)
     g = gpu_ctx_factory()
-    monkeypatch.delenv("HESS_HOST_DIRECT")
-    g2 = gpu_ctx_factory()
+    monkeypatch.delenv("HESS_DELIVERY")
+    imgs = np.stack([fixtures.load_rgb(n) for n in fixtures.list640()[:3]])
     o = OracleSession(threads=8, keep_levels=False)
-    _compare_all(g, o, imgs, "copy delivery", stages=False)
-    _compare_all(g2, o, imgs, "direct delivery", stages=False)
+    _compare_all(g, o, imgs, f"{mode} delivery, batch of 3", stages=False)
+    _compare_all(g, o, imgs[:1], f"{mode} delivery, one image", stages=False)
+    _compare_all(g, o, imgs[1:], f"{mode} delivery, batch of 2", stages=False)
+
+
+def test_result_delivery_default_switches_with_batch_size(gpu_ctx_factory):
+    """Default policy: batches of one or two images use the in-kernel mirror, larger ones the copier thread; a context
+    that alternates between them (and pipelines submit/wait pairs) keeps delivering the oracle's results."""
+    g = gpu_ctx_factory()
+    imgs = np.stack([fixtures.load_rgb(n) for n in fixtures.list640()[:4]])
+    o = OracleSession(threads=8, keep_levels=False)
+    for sel in ([0, 1, 2, 3], [2], [0, 1, 2], [3, 1], [0, 1, 2, 3]):
+        _compare_all(g, o, imgs[sel], f"default delivery, images {sel}", stages=False)
+    # submit/wait with the copier: results of the batch submitted last
+    g.submit_host(imgs)
+    g.wait()
+    o.run(imgs)
+    for b in range(4):
+        gk, gd = g.fetch(b)
+        ok, od = o.fetch(b)
+        _assert_same_features(gk, gd, ok, od, f"submit/wait img {b}")
+
+
+@pytest.mark.parametrize("mode", ["mirror", "dma", "blit"])
+def test_feature_storage_grows_on_overflow(gpu_ctx_factory, monkeypatch, mode):
+    """The reference grows its per-level lists on demand (SetLevelFeatureNum, PyramidCU.cpp:393-397); here a batch
+    that overflows the raw-detection or the feature storage raises a device flag, the storage grows and the batch
+    runs again (hess_pipeline.hip, wait_impl).  HESS_INITIAL_CAP=64 makes a new context start with room for 64
+    detections per image, so that dense noise at a low threshold overflows both lists -- with every delivery mode,
+    for one image and for a batch, with and without top-K."""
+    monkeypatch.setenv("HESS_INITIAL_CAP", "64")
+    monkeypatch.setenv("HESS_DELIVERY", mode)
+    rng = np.random.RandomState(11)
+    imgs = (rng.rand(3, 120, 200) * 255).astype(np.uint8)
+    kw = dict(dog_threshold=0.0005, edge_threshold=50.0)
+    g = gpu_ctx_factory(**kw)
+    o = OracleSession(threads=8, keep_levels=False, **kw)
+    n = _compare_all(g, o, imgs, f"grown storage ({mode})", stages=False)
+    assert min(n) > 64 * 4 and g.regrown() >= 1          # both lists had to grow (orientations included)
+    grown = g.regrown()
+    _compare_all(g, o, imgs, f"grown storage ({mode}), again", stages=False)
+    assert g.regrown() == grown                           # grow-only: the second run fits
+    kt = dict(kw, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
+    gt = gpu_ctx_factory(**kt)
+    ot = OracleSession(threads=8, keep_levels=False, **kt)
+    _compare_all(gt, ot, imgs[:1], f"grown storage ({mode}), top-K", stages=False)
+    assert gt.regrown() >= 1
+
+
+def test_refused_reservation_leaves_the_context_usable(gpu_ctx_factory):
+    """hess_reserve of more memory than the device has returns HESS_ERR_NOMEM (no abort, no exception across the C
+    ABI) and the context still runs afterwards, with the right results."""
+    from hessgpu_amd.session import HessError
+    g = gpu_ctx_factory()
+    o = OracleSession(threads=8, keep_levels=False)
+    img = fixtures.load_rgb("640-2.jpg")
+    _compare_all(g, o, img[None], "before the refused reservation", stages=False)
+    with pytest.raises(HessError) as e:
+        g.reserve(1920, 1080, 200000)                     # 2.2e13 bytes of planes
+    assert e.value.code == _abi.HESS_ERR_NOMEM
+    _compare_all(g, o, img[None], "after the refused reservation", stages=False)
+    g.reserve(1920, 1080, 2)
+    _compare_all(g, o, img[None], "after a reservation that fits", stages=False)
+
+
+def test_pageable_batch_of_1080p_images_through_the_helper_threads(gpu_ctx_factory):
+    """hess_run_host from pageable memory stages inputs of 16 MB and more with four threads (hess_submit_host); a
+    batch of eight 1080p images (16.6 MB) takes that path.  Image 0 and 7 against the oracle, and every image
+    against the same pixels run one at a time."""
+    imgs = np.stack([fixtures.synthetic_blobs(1920, 1080, i) for i in range(2)] * 4)   # pageable numpy memory
+    imgs[7] = imgs[7][::-1]                                                           # make the last one distinct
+    kw = dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=4096)
+    g = gpu_ctx_factory(**kw)
+    counts = g.run(imgs)
+    res = [g.fetch(b) for b in range(8)]
+    o = OracleSession(threads=8, keep_levels=False, **kw)
+    for b in (0, 7):
+        o.run(imgs[b:b + 1])
+        ok, od = o.fetch(0)
+        _assert_same_features(res[b][0], res[b][1], ok, od, f"pageable batch img {b}")
+    g1 = gpu_ctx_factory(**kw)
+    for b in range(8):
+        assert g1.run(imgs[b:b + 1]) == [counts[b]]
+        k, d = g1.fetch(0)
+        assert k.tobytes() == res[b][0].tobytes() and d.tobytes() == res[b][1].tobytes()
 
 
 def test_edge_cases(gpu_ctx_factory):
