@@ -56,11 +56,12 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2.0     # nominal: 256 CUs x 4 SIMDs, one wave64 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[3]: 64 images over 8 GPUs)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images per GPU (0 = --batch: all distinct)")
-    ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) pipelined per GPU")
+    ap.add_argument("--contexts", type=int, default=6, help="contexts (streams) pipelined per GPU (with the copier-thread delivery a "
+                    "context's stream idles while its results are copied: six keep the device busy, profiles/r03_delivery.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")

@@ -19,6 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
             "-Wno-unused-function", f"--offload-arch={ARCH}"] + os.environ.get("HESS_EXTRA_FLAGS", "").split()
 
+# ROCr itself, beside the HIP runtime: the copier thread hands its device->host copies straight to an SDMA engine
+# (hsa_amd_memory_async_copy_on_engine, csrc/hess_pipeline.hip)
+LINK_LIBS = ["-lhsa-runtime64"]
 KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_pipeline.hip", "hess_match.hip"]
 # Per-file flags.  k_feature.hip: the SLP vectoriser turns pairs of FP32 operations into packed
 # instructions (v_pk_add/mul/fma_f32), which on gfx950 issue at half rate (tools/micro/README.md) and need
@@ -55,7 +58,7 @@ def build_variant(name, extra_flags, verbose=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(_run, jobs))
     lib = os.path.join(vdir, "libhessgpu.so")
-    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + LINK_LIBS)
     for o in objs:
         os.remove(o)
     if verbose:
@@ -78,7 +81,7 @@ def build_all(force=False, verbose=False):
         list(ex.map(_run, jobs))
     lib = os.path.join(HERE, "libhessgpu.so")
     if force or jobs or not os.path.exists(lib):
-        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + LINK_LIBS)
     built = [lib]
     api_src = os.path.join(CSRC, "siftgpu_api.cpp")
     if os.path.exists(api_src):

@@ -9,6 +9,8 @@
 // call, every stage enqueued without host synchronisation, a single device->host transfer of the
 // counts followed by one of the results; feature-list order is deterministic (level, row, col).
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -68,10 +70,13 @@ struct PendingRun {
 //                   kernel): no command after the kernels, the shortest path for one image -- but a kernel that waits
 //                   for the link holds up the memory path of whatever runs beside it;
 //   kDeliverDma     a per-context copier thread waits on the host for the event behind the descriptor kernel, reads
-//                   the exact byte count from the pinned count block and issues the copy on a stream that never
-//                   carries a kernel and has no dependency on one: the runtime then uses the DMA engine (a
-//                   device->host copy that FOLLOWS kernels in stream order is executed as a blit kernel instead,
-//                   which is the same PCIe-bound shader copy as the mirror); hess_wait waits for that copy;
+//                   the exact byte count from the pinned count block and hands the copy to an SDMA engine through
+//                   ROCr itself (hsa_amd_memory_async_copy_on_engine), then waits for its completion signal; hess_wait
+//                   waits for the thread.  Not hipMemcpyAsync: HIP streams share four hardware queues, so a "copy-only"
+//                   stream lands on the queue of some context's kernels, where this runtime executes the copy as a
+//                   blit kernel behind them (profiles/r03_*: __amd_rocclr_copyBuffer from the copier's stream) -- the
+//                   same PCIe-bound shader copy as the mirror.  hipMemcpyAsync on a copy stream remains the fallback
+//                   when ROCr refuses (HESS_COPIER=hip selects it for A/B runs);
 //   kDeliverBlit    hipMemcpyAsync on the context's stream after hess_wait has read the counts (the fallback, and
 //                   what the reference does per level, PyramidCU.cpp:509-532).
 enum { kDeliverMirror = 0, kDeliverDma = 1, kDeliverBlit = 2 };
@@ -85,8 +90,13 @@ struct Copier {
   int rc = 0;            // result of the last job (hess_status)
   bool overflow = false; // the batch overflowed its feature storage: nothing was copied
   std::string err;
-  hipStream_t cs = nullptr;     // copy-only stream
+  hipStream_t cs = nullptr;     // copy-only stream (fallback path)
   hipEvent_t ev_done = nullptr; // recorded on the context's stream behind the last kernel of a batch
+  // ROCr side (SDMA): agents owning the device / pinned host buffers, engine, completion signal
+  bool hsa_ready = false, hsa_failed = false;
+  hsa_agent_t gpu_agent{}, cpu_agent{};
+  uint32_t engine = 0;          // hsa_amd_sdma_engine_id_t bit, 0 = let ROCr choose
+  hsa_signal_t sig{};
 };
 
 struct hess_ctx {
@@ -768,6 +778,64 @@ int enqueue_user(hess_ctx* c) {
 // ---- copier thread (kDeliverDma) ----
 // One job at a time: wait on the host for the event behind the batch's last kernel, read the packed total from the
 // pinned count block (stored there by feature_scan_kernel), copy exactly that many records on the copy-only stream.
+std::atomic<int> g_copier_count{0};  // contexts with a copier, for spreading them over the preferred engines
+
+// Bind the copier to ROCr: the agents that own the result buffers (from the pointers themselves), an SDMA engine of
+// the set ROCr recommends for device->host on this pair of agents (contexts take turns), a completion signal.
+bool copier_hsa_setup(hess_ctx* c) {
+  Copier& cp = c->cp;
+  if (cp.hsa_ready) return true;
+  if (cp.hsa_failed) return false;
+  cp.hsa_failed = true;
+  if (const char* m = getenv("HESS_COPIER")) if (!strcmp(m, "hip")) return false;
+  if (hsa_init() != HSA_STATUS_SUCCESS) return false;  // reference-counted: HIP has initialised ROCr already
+  hsa_amd_pointer_info_t pi;
+  memset(&pi, 0, sizeof(pi));
+  pi.size = sizeof(pi);
+  if (hsa_amd_pointer_info(c->keys.p, &pi, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pi.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+  cp.gpu_agent = pi.agentOwner;
+  memset(&pi, 0, sizeof(pi));
+  pi.size = sizeof(pi);
+  if (hsa_amd_pointer_info(c->h_keys.p, &pi, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pi.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+  cp.cpu_agent = pi.agentOwner;
+  if (hsa_signal_create(0, 0, nullptr, &cp.sig) != HSA_STATUS_SUCCESS) return false;
+  uint32_t pref = 0;
+  if (hsa_amd_memory_get_preferred_copy_engine(cp.cpu_agent, cp.gpu_agent, &pref) == HSA_STATUS_SUCCESS && pref) {
+    const int n = __builtin_popcount(pref), k = g_copier_count.fetch_add(1) % n;
+    uint32_t m = pref;
+    for (int i = 0; i < k; i++) m &= m - 1;
+    cp.engine = m & (~m + 1);
+  }
+  if (const char* e = getenv("HESS_COPIER_ENGINE")) cp.engine = (uint32_t)strtoul(e, nullptr, 0);
+  cp.hsa_failed = false;
+  cp.hsa_ready = true;
+  return true;
+}
+
+// keys + descriptors of `total` features to the pinned host buffers by SDMA; false: ROCr refused, use the fallback
+bool copier_hsa_copy(hess_ctx* c, size_t total) {
+  Copier& cp = c->cp;
+  const int ncopy = c->dim ? 2 : 1;
+  hsa_signal_store_relaxed(cp.sig, ncopy);
+  auto one = [&](void* dst, const void* src, size_t bytes) {
+    hsa_status_t st = cp.engine
+        ? hsa_amd_memory_async_copy_on_engine(dst, cp.cpu_agent, src, cp.gpu_agent, bytes, 0, nullptr, cp.sig,
+                                              (hsa_amd_sdma_engine_id_t)cp.engine, false)
+        : hsa_amd_memory_async_copy(dst, cp.cpu_agent, src, cp.gpu_agent, bytes, 0, nullptr, cp.sig);
+    if (st != HSA_STATUS_SUCCESS && cp.engine)  // engine busy or not available: let ROCr choose
+      st = hsa_amd_memory_async_copy(dst, cp.cpu_agent, src, cp.gpu_agent, bytes, 0, nullptr, cp.sig);
+    return st == HSA_STATUS_SUCCESS;
+  };
+  if (!one(c->h_keys.p, c->keys.p, total * sizeof(HostKeypoint))) return false;
+  if (c->dim && !one(c->h_desc.p, c->desc.p, total * c->dim * 4)) {
+    // the first copy is in flight and will decrement the signal once: wait for it, then report failure
+    while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, ncopy, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= ncopy) {}
+    return false;
+  }
+  while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+  return true;
+}
+
 void copier_main(hess_ctx* c) {
   Copier& cp = c->cp;
   (void)hipSetDevice(c->device);
@@ -799,12 +867,17 @@ void copier_main(hess_ctx* c) {
             rc = HESS_ERR_NOMEM;
           }
         }
+        const bool by_sdma = !rc && copier_hsa_setup(c) && copier_hsa_copy(c, total);
+        if (by_sdma) {
+          // done: both blocks are in host memory
+        } else {
         if (!rc && (e = hipMemcpyAsync(hk->p, c->keys.p, total * sizeof(HostKeypoint), hipMemcpyDeviceToHost, cp.cs)) != hipSuccess)
           fail("hipMemcpyAsync(keys)", e);
         if (!rc && c->dim &&
             (e = hipMemcpyAsync(hd->p, c->desc.p, total * c->dim * 4, hipMemcpyDeviceToHost, cp.cs)) != hipSuccess)
           fail("hipMemcpyAsync(desc)", e);
         if (!rc && (e = hipStreamSynchronize(cp.cs)) != hipSuccess) fail("hipStreamSynchronize(copy stream)", e);
+        }
       }
     }
     lk.lock();
@@ -844,6 +917,7 @@ void copier_stop(hess_ctx* c) {
     cp.th.join();
     cp.started = false;
   }
+  if (cp.hsa_ready) { (void)hsa_signal_destroy(cp.sig); cp.hsa_ready = false; }
   if (cp.cs) { (void)hipStreamDestroy(cp.cs); cp.cs = nullptr; }
   if (cp.ev_done) { (void)hipEventDestroy(cp.ev_done); cp.ev_done = nullptr; }
 }

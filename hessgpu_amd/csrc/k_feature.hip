@@ -18,6 +18,7 @@
 //                of its cell and adds the iteration's samples to them through a per-wavefront LDS coefficient
 //                table (see descriptor_kernel).
 // Built without the SLP vectoriser (hessgpu_amd/build.py): packed FP32 issues at half rate on gfx950.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hess_dev.h"

@@ -101,7 +101,7 @@ int main() {
       {"one CU, 1 wave/SIMD", 1, 256, 0, 1, false},    {"one CU, 2 waves/SIMD", 1, 512, 0, 2, false},
       {"one CU, 4 waves/SIMD", 1, 1024, 0, 4, false},  {"all CUs, 1 wave/SIMD", ncu, 256, 80 * 1024, 1, true},
       {"all CUs, 2 waves/SIMD", ncu, 512, 80 * 1024, 2, true}, {"all CUs, 4 waves/SIMD", ncu, 1024, 80 * 1024, 4, true},
-      {"all CUs, 8 waves/SIMD", 2 * ncu, 1024, 80 * 1024, 8, true},
+      {"all CUs, 8 waves/SIMD", 2 * ncu, 1024, 64 * 1024, 8, true},
   };
   struct K { const char* name; Kern fn; int per_iter; } kernels[] = {
       {"v_fma_f32", k_fma, 64},   {"v_mul_f32", k_mul, 64},         {"v_add_f32", k_add, 64},
@@ -111,15 +111,23 @@ int main() {
   };
   for (auto& k : kernels) CHECK(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   printf("# MI355X vector-ALU issue: cycles per wave64 instruction and SIMD, clock held, sustained rate (CUs: %d)\n", ncu);
-  printf("%-16s %-24s %10s %10s %12s %14s\n", "instruction", "configuration", "cyc/inst", "clock GHz", "Ginst/s", "chip-equiv");
+  printf("%-16s %-24s %10s %10s %12s %14s %14s\n", "instruction", "configuration", "cyc/inst", "clock GHz", "Ginst/s", "chip-equiv",
+         "wall Ginst/s");
+  hipEvent_t ev0, ev1;
+  CHECK(hipEventCreate(&ev0));
+  CHECK(hipEventCreate(&ev1));
   const int iters = 20000;  // 64 x 20000 = 1.28 M instructions per wave: 1-10 ms per launch
   for (auto& k : kernels) {
     for (auto& c : cfgs) {
       const auto t0 = std::chrono::steady_clock::now();
       int launches = 0;
+      float wall_ms = 0;
       while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.4 || launches < 3) {
+        CHECK(hipEventRecord(ev0, 0));
         hipLaunchKernelGGL(k.fn, dim3(c.blocks), dim3(c.threads), c.lds, 0, st, out, 1.0001f, 0.5f, iters);
+        CHECK(hipEventRecord(ev1, 0));
         CHECK(hipDeviceSynchronize());
+        CHECK(hipEventElapsedTime(&wall_ms, ev0, ev1));
         launches++;
       }
       const int nw = c.blocks * c.threads / 64;
@@ -135,7 +143,10 @@ int main() {
       const int simds = (c.all ? ncu : 1) * 4;
       const double rate = simds * ghz / cpi;          // Ginst/s of the SIMDs in use
       const double chip = ncu * 4 * ghz / cpi;        // the same cycles and clock on every SIMD of the chip
-      printf("%-16s %-24s %10.2f %10.3f %12.1f %14.1f\n", k.name, c.name, cpi, ghz, rate, chip);
+      // independent of the stamps: every instruction of the launch over the launch's wall time (hipEvents): if the
+      // workgroups of a configuration were not all resident at once this is what shows it
+      const double wall = insts * (double)nw / (wall_ms * 1e-3) / 1e9;
+      printf("%-16s %-24s %10.2f %10.3f %12.1f %14.1f %14.1f\n", k.name, c.name, cpi, ghz, rate, chip, wall);
       fflush(stdout);
     }
   }
