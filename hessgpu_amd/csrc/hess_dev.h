@@ -141,9 +141,10 @@ void launch_downsample(hipStream_t st, const float* src, int sw, int splane, flo
 void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gauss, float* deth,
                     float* got, const float* norms /* host: sigma^4 per level */, int batch,
                     int level_first, int level_last);
-// det-H of level `level` of every octave, one launch (no gradient plane)
+// det-H of level `level` of every octave, one launch (no gradient plane); also clears `zero_bytes` (a multiple of 16)
+// at `zero` if given: the buffers the detection stages expect zeroed
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch);
+                          int batch, void* zero = nullptr, size_t zero_bytes = 0);
 
 // Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

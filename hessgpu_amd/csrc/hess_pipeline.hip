@@ -99,6 +99,28 @@ struct Copier {
   hsa_signal_t sig{};
 };
 
+// Persistent helper threads that copy pageable input pixels into the context's pinned staging buffer
+// (hess_submit_host).  The calling thread walks the chunks in ascending order -- staging the ones nobody has claimed,
+// enqueueing every chunk's transfer as soon as it is staged -- while the helpers claim chunks from the END, so the
+// early chunks are ready first.  Started at the first pageable submission, reused afterwards: starting threads per
+// call cost more than staging one image.
+struct Stager {
+  static constexpr int kHelpers = 3;
+  std::thread th[kHelpers];
+  int nth = 0;
+  bool tried = false;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  bool stop = false;
+  unsigned long long gen = 0;
+  const char* src = nullptr;
+  char* dst = nullptr;
+  size_t bytes = 0, chunk = 0;
+  int nchunk = 0, active = 0;
+  std::vector<std::atomic<int>> state;  // per chunk: 0 free, 1 claimed, 2 staged
+  std::atomic<int> next_hi{-1};
+};
+
 struct hess_ctx {
   int device = 0;
   hipStream_t st = nullptr;
@@ -122,6 +144,7 @@ struct hess_ctx {
   // overflow flags, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
   DevBuf zeroed;
   size_t zeroed_used = 0;
+  bool zero_filled = false;  // the running batch's det-H launch has cleared `zeroed`
   struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist;
   // host results
   int batch = 0;
@@ -140,6 +163,7 @@ struct hess_ctx {
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   Copier cp;
+  Stager sg;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
   // user-supplied keypoint list (SiftPyramid::SetKeypointList): used by the next run, then cleared
   std::vector<hess_keypoint> user_keys;
@@ -155,6 +179,7 @@ struct hess_ctx {
   int cap_list = 0;
   float timing[HESS_T_COUNT];
   hipEvent_t ev[8];
+  bool stage_events = false;  // events between the stages of the running batch (each costs a ~6 us bubble on the stream)
   bool have_ev = false;
   std::string err;
   // profiling
@@ -175,7 +200,7 @@ void set_err(hess_ctx* c, const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   c->err = buf;
-  if (c->p.verbose) fprintf(stderr, "hessgpu: %s\n", buf);
+  if (c->p.verbose & 1) fprintf(stderr, "hessgpu: %s\n", buf);
 }
 
 #define HIP_TRY(c, expr)                                                                  \
@@ -509,6 +534,10 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   float* got = (float*)c->got.p;
   auto plane_ptr = [&](float* base, int o, int l) { return base + g.o[o].lvl_off + (long long)l * g.B * g.o[o].plane; };
 
+  // Stage timers (SiftGPU::_timing[2..10]) only when asked for: hess_params.verbose bit 1 (the reference's _timingS,
+  // SiftGPU.cpp:433-464: its stage times, too, are only meaningful when it synchronises at stage ends) or the bench's
+  // per-kernel profile.  An event record between two kernels leaves the stream idle for about 6 us.
+  c->stage_events = (c->p.verbose & 2) != 0;
   HIP_TRY(c, hipEventRecord(c->ev[0], st));
   const bool user_mode = !c->user_keys.empty();
   if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
@@ -562,16 +591,21 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                    decim ? plane_ptr(gauss, o + 1, 0) : nullptr, decim ? g.o[o + 1].wa : 0, decim ? g.o[o + 1].h : 0);
     }
   }
-  HIP_TRY(c, hipEventRecord(c->ev[1], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
   {  // the octaves' top levels have no successor blur: one standalone launch for all of them
     double px = 0;
     for (int o = 0; o < g.noct; o++) px += g.o[o].plane;
     ProfScope ps(c, HESS_K_HESSIAN, (double)batch * px * 8.0);
-    if (s.level_max >= 1 && s.level_max <= g.dog)  // (never with the reference's level layout: level_max = dog + 1)
+    c->zero_filled = false;
+    if (s.level_max >= 1 && s.level_max <= g.dog) {  // (never with the reference's level layout: level_max = dog + 1)
       for (int o = 0; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
-    else
-      launch_hessian_level(st, g, gauss, deth, s.level_max, s.norm[s.level_max], batch);
+    } else {
+      // this launch also clears the buffers of the detection stages (no fill launch of its own in the chain)
+      launch_hessian_level(st, g, gauss, deth, s.level_max, s.norm[s.level_max], batch, user_mode ? nullptr : c->zeroed.p,
+                           c->zeroed_used);
+      c->zero_filled = !user_mode;
+    }
   }
   }  // !(user_mode && on_current)
   if (user_mode) return enqueue_user(c);
@@ -584,7 +618,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   LimitParams lp;
   lp.method = p.truncate_method;
   lp.threshold = p.feature_count_threshold;
-  HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, c->zeroed_used, st));  // overflow flags, row counts, histogram, masks
+  if (!c->zero_filled)  // overflow flags, row counts, histogram, masks (normally cleared by the det-H launch above)
+    HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, c->zeroed_used, st));
   {
     // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
     double det_bytes = 0;
@@ -592,7 +627,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
     launch_extrema_mark(st, g, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
   }
-  HIP_TRY(c, hipEventRecord(c->ev[2], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
   launch_row_scan(st, g, lp, (const int*)c->rowcnt.p, (int*)c->rowoff.p, (int*)c->level_count.p,
                   (int*)c->raw_total.p, c->cap_raw, (int*)c->overflow.p, batch);
   {
@@ -601,7 +636,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                            (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch,
                            c->use_topk ? (unsigned*)c->hist.p : nullptr, p.feature_count_threshold);
   }
-  HIP_TRY(c, hipEventRecord(c->ev[3], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[3], st));
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
   const RawKey* list = (const RawKey*)c->raw.p;
   const int* list_total = (const int*)c->raw_total.p;
@@ -618,7 +653,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   c->d_list = list;
   c->d_list_total = list_total;
   c->cap_list = cap_list;
-  HIP_TRY(c, hipEventRecord(c->ev[4], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[4], st));
   // ---- orientation (GetFeatureOrientations) ----
   OrientParams op;
   op.gaussian_factor = p.orient_gaussian_factor;
@@ -633,12 +668,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_ORIENT, 0.0);
     launch_orientation(st, g, op, list, list_total, cap_list, got, (FRec*)c->recs.p, (int*)c->ocount.p, batch);
   }
-  HIP_TRY(c, hipEventRecord(c->ev[5], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[5], st));
   // ---- multi-orientation expansion (ReshapeFeatureListCPU) ----
   launch_feature_scan(st, g, lp, c->multi ? 1 : 0, list, list_total, cap_list, (const int*)c->ocount.p,
                       (int*)c->foffset.p, (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p, (int*)c->img_base.p, (int*)c->h_small.p, batch);
-  HIP_TRY(c, hipEventRecord(c->ev[6], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[6], st));
   // ---- descriptors (GetFeatureDescriptors) ----
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
@@ -735,7 +770,7 @@ int enqueue_user(hess_ctx* c) {
   c->d_list = list;
   c->d_list_total = list_total;
   c->cap_list = c->cap_raw;
-  for (int e = 1; e <= 4; e++) HIP_TRY(c, hipEventRecord(c->ev[e], st));
+  if (c->stage_events) for (int e = 1; e <= 4; e++) HIP_TRY(c, hipEventRecord(c->ev[e], st));
   float* got = (float*)c->got.p;
   if (!c->user_have_orientation) {
     OrientParams op;
@@ -749,14 +784,14 @@ int enqueue_user(hess_ctx* c) {
     for (int l = 0; l < kMaxLev; l++) op.level_sigma[l] = l <= s.level_max ? s.level_sigma[l] : 0.0f;
     launch_orientation(st, g, op, list, list_total, c->cap_raw, got, (FRec*)c->recs.p, (int*)c->ocount.p, 1);
   }
-  HIP_TRY(c, hipEventRecord(c->ev[5], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[5], st));
   LimitParams lp;
   lp.method = 0;
   lp.threshold = -1;  // LimitFeatureCount returns at once for existing keypoints (SiftPyramid.cpp:203)
   launch_feature_scan(st, g, lp, 0, list, list_total, c->cap_raw, (const int*)c->ocount.p, (int*)c->foffset.p,
                       (int*)c->fsrc.p, (int*)c->feat_total.p, (int*)c->feat_first.p, c->cap_feat,
                       (int*)c->overflow.p, (int*)c->img_base.p, (int*)c->h_small.p, 1);
-  HIP_TRY(c, hipEventRecord(c->ev[6], st));
+  if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[6], st));
   DescParams dsp;
   dsp.window_factor = p.desc_window_factor;
   dsp.half_sift = p.half_sift;
@@ -773,6 +808,52 @@ int enqueue_user(hess_ctx* c) {
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
   HIP_TRY(c, hipEventRecord(c->ev[7], st));
   return 0;
+}
+
+// ---- staging helpers (hess_submit_host, pageable input) ----
+void stager_copy(Stager& sg, int k) {
+  const size_t off = (size_t)k * sg.chunk, len = std::min(sg.chunk, sg.bytes - off);
+  memcpy(sg.dst + off, sg.src + off, len);
+  { std::lock_guard<std::mutex> lk(sg.mu); sg.state[k].store(2, std::memory_order_release); }
+  sg.cv_done.notify_all();
+}
+
+void stager_main(Stager* sgp) {
+  Stager& sg = *sgp;
+  unsigned long long seen = 0;
+  std::unique_lock<std::mutex> lk(sg.mu);
+  for (;;) {
+    sg.cv_job.wait(lk, [&] { return sg.stop || sg.gen != seen; });
+    if (sg.stop) return;
+    seen = sg.gen;
+    lk.unlock();
+    for (;;) {
+      const int k = sg.next_hi.fetch_sub(1, std::memory_order_acq_rel);
+      if (k < 0) break;
+      int expect = 0;
+      if (sg.state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) stager_copy(sg, k);
+      else break;  // met the calling thread coming up: everything is claimed
+    }
+    lk.lock();
+    sg.active--;
+    sg.cv_done.notify_all();
+  }
+}
+
+void stager_start(Stager& sg) {
+  if (sg.tried) return;
+  sg.tried = true;
+  for (int t = 0; t < Stager::kHelpers; t++) {
+    try { sg.th[sg.nth] = std::thread(stager_main, &sg); sg.nth++; } catch (...) { break; }  // fewer helpers: the caller copies more
+  }
+}
+
+void stager_stop(Stager& sg) {
+  if (!sg.nth) return;
+  { std::lock_guard<std::mutex> lk(sg.mu); sg.stop = true; }
+  sg.cv_job.notify_all();
+  for (int t = 0; t < sg.nth; t++) sg.th[t].join();
+  sg.nth = 0;
 }
 
 // ---- copier thread (kDeliverDma) ----
@@ -984,7 +1065,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
     if (of_feat) c->cap_feat = of_feat + of_feat / 4;
     c->planned = false;
     c->regrown++;
-    if (c->p.verbose) fprintf(stderr, "hessgpu: feature storage grown (raw %d, features %d)\n", c->cap_raw, c->cap_feat);
+    if (c->p.verbose & 1) fprintf(stderr, "hessgpu: feature storage grown (raw %d, features %d)\n", c->cap_raw, c->cap_feat);
     if ((rc = submit_impl(c, r))) return rc;
   }
   drain_profile(c);
@@ -1030,13 +1111,15 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
   auto el = [&](int i, int j) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; };
   c->timing[HESS_T_LOAD] = (float)r.t_load_ms;
   if (r.timed_load) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_load[0], c->ev_load[1]); c->timing[HESS_T_LOAD] = ms; }
-  c->timing[HESS_T_PYRAMID] = el(0, 1);
-  c->timing[HESS_T_DETECT] = el(1, 2);
-  c->timing[HESS_T_LIST] = el(2, 3);
-  c->timing[HESS_T_REDUCTION] = el(3, 4);
-  c->timing[HESS_T_ORIENT] = el(4, 5);
-  c->timing[HESS_T_MULTI_ORIENT] = el(5, 6);
-  c->timing[HESS_T_DESCRIPTOR] = el(6, 7);
+  if (c->stage_events) {
+    c->timing[HESS_T_PYRAMID] = el(0, 1);
+    c->timing[HESS_T_DETECT] = el(1, 2);
+    c->timing[HESS_T_LIST] = el(2, 3);
+    c->timing[HESS_T_REDUCTION] = el(3, 4);
+    c->timing[HESS_T_ORIENT] = el(4, 5);
+    c->timing[HESS_T_MULTI_ORIENT] = el(5, 6);
+    c->timing[HESS_T_DESCRIPTOR] = el(6, 7);
+  }
   c->timing[HESS_T_TOTAL] = el(0, 7) + c->timing[HESS_T_LOAD];
   return 0;
 }
@@ -1107,6 +1190,7 @@ void hess_destroy(hess_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
   copier_stop(c);
+  stager_stop(c->sg);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
                     &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
@@ -1196,52 +1280,45 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
     (void)hipGetLastError();  // an unregistered pointer is reported as an error: not one
     if ((rc = ensure(c, c->h_stage, bytes, true))) return rc;
     // Pageable memory: copied into the pinned staging buffer in chunks, each chunk's transfer enqueued as soon as
-    // it is staged, so the copy engine works while the next chunk is being copied.  Large inputs are staged by a
-    // few helper threads (one core copies at about 17 GB/s, a third of what the link takes).
-    // 4 MB chunks; a small input (one image) is cut in four so that its transfer, too, overlaps its staging.
-    // Chunks are claimed (0 -> 1) by whichever thread gets there first and marked done (2) under the mutex; the
-    // calling thread walks them in order, copies the ones nobody has claimed and otherwise sleeps on the
-    // condition variable until the claimer is done.  A helper that cannot be started is simply missing: the
-    // calling thread then copies its share (nothing thrown crosses the C ABI).
+    // it is staged, so the copy engine works while the next chunks are being copied (one core copies at about
+    // 17 GB/s, a third of what the link takes: the context's helper threads share the work, see Stager).
+    // 4 MB chunks; a small input (one image) is cut in four so that its transfer, too, overlaps its staging, and is
+    // staged by the calling thread alone: waking the helpers costs more than they save below about 8 MB (one 1080p
+    // image: 0.544 ms per call alone, 0.58 ms with helpers; profiles/r03_host_path.json).
+    // Nothing here allocates or throws once the helpers exist (nothing thrown crosses the C ABI).
+    Stager& sg = c->sg;
     const size_t chunk = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)256 << 10, ((bytes / 4 + 65535) >> 16) << 16));
     const int nchunk = (int)((bytes + chunk - 1) / chunk);
-    const int nthreads = bytes >= ((size_t)16 << 20) ? 4 : (bytes >= ((size_t)8 << 20) ? 2 : 1);  // helpers only where they pay for their start
-    std::atomic<int>* state = new (std::nothrow) std::atomic<int>[nchunk];
-    if (!state) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
-    for (int k = 0; k < nchunk; k++) state[k].store(0, std::memory_order_relaxed);
-    std::mutex mu;
-    std::condition_variable cv;
-    auto copy_chunk = [&](int k) {
-      const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
-      memcpy((char*)c->h_stage.p + off, (const char*)pixels + off, len);
-      { std::lock_guard<std::mutex> lk(mu); state[k].store(2, std::memory_order_release); }
-      cv.notify_all();
-    };
-    auto helper = [&](int first) {  // a helper prefers its own residue class, so the threads do not fight over chunks
-      for (int k = first; k < nchunk; k += nthreads) {
-        int expect = 0;
-        if (state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) copy_chunk(k);
-      }
-    };
-    std::thread helpers[3];
-    int nstarted = 0;
-    for (int t = 1; t < nthreads; t++) {
-      try { helpers[nstarted] = std::thread(helper, t); nstarted++; } catch (...) { /* no helper: this thread copies */ }
+    const bool helped = bytes >= ((size_t)8 << 20) && nchunk > 1;
+    if (helped) stager_start(sg);
+    try {
+      if ((int)sg.state.size() < nchunk) { std::vector<std::atomic<int>> grown(nchunk); sg.state.swap(grown); }
+    } catch (...) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
+    {
+      std::lock_guard<std::mutex> lk(sg.mu);
+      for (int k = 0; k < nchunk; k++) sg.state[k].store(0, std::memory_order_relaxed);
+      sg.src = (const char*)pixels; sg.dst = (char*)c->h_stage.p; sg.bytes = bytes; sg.chunk = chunk; sg.nchunk = nchunk;
+      sg.next_hi.store(helped ? nchunk - 1 : -1, std::memory_order_release);
+      sg.active = helped ? sg.nth : 0;
+      if (helped && sg.nth) sg.gen++;
     }
+    if (helped && sg.nth) sg.cv_job.notify_all();
     hipError_t cerr = hipSuccess;
     for (int k = 0; k < nchunk; k++) {
       int expect = 0;
-      if (state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) copy_chunk(k);
-      else if (state[k].load(std::memory_order_acquire) != 2) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return state[k].load(std::memory_order_acquire) == 2; });
+      if (sg.state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) stager_copy(sg, k);
+      else if (sg.state[k].load(std::memory_order_acquire) != 2) {
+        std::unique_lock<std::mutex> lk(sg.mu);
+        sg.cv_done.wait(lk, [&] { return sg.state[k].load(std::memory_order_acquire) == 2; });
       }
       const size_t off = (size_t)k * chunk, len = std::min(chunk, bytes - off);
       if (cerr == hipSuccess)
         cerr = hipMemcpyAsync((char*)c->stage.p + off, (const char*)c->h_stage.p + off, len, hipMemcpyHostToDevice, c->st);
     }
-    for (int t = 0; t < nstarted; t++) helpers[t].join();
-    delete[] state;
+    {  // the helpers are done with this job's bookkeeping before the next one rewrites it
+      std::unique_lock<std::mutex> lk(sg.mu);
+      sg.cv_done.wait(lk, [&] { return sg.active == 0; });
+    }
     HIP_TRY(c, cerr);
   }
   HIP_TRY(c, hipEventRecord(c->ev_load[1], c->st));

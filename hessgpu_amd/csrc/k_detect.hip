@@ -18,6 +18,8 @@
 //                  (level,row,col) order, deterministic;
 //   topk           15-bit histogram of abs(half(response)) -> exact cut, then one ordered
 //                  compaction pass (ties at the cut resolved towards the lower list index).
+#include <cstddef>
+
 #include "hess_dev.h"
 #include "hess_devmath.h"
 
@@ -131,7 +133,16 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
 // adjacent lanes, and from explicit 1-D-indexed loads at row ends and wavefront edges.
 // det-H of one level of every octave in a single launch (the octaves' top levels: nobody's source level, so no
 // Gaussian launch computes it on the side).  1 thread = 4 px x 4 rows; neighbour columns from the adjacent lanes.
-__global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm) {
+__global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm,
+                                                            uint4* zero, long long zero_n) {
+  // On the side: clear what the detection stages expect zeroed (overflow words, row counts, top-K histogram, extrema
+  // masks: one allocation, hess_pipeline.hip) -- a grid-stride fill by this launch's threads instead of a fill
+  // launch of its own in the dependent chain.
+  if (zero) {
+    const long long nthr = (long long)gridDim.x * gridDim.y * 256;
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_n; i += nthr)
+      zero[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   int blk = blockIdx.x, o = 0;  // block -> octave: octaves back to back, whole blocks each (uniform scalar walk)
   for (; o < g.noct - 1; o++) {
     const int nb = ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
@@ -959,20 +970,37 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const 
     int tseen = ties0 + etie;                                  // ties before this thread's entries
     int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
     int run_level = -1, run = 0;  // kept entries per level: one LDS atomic per run of equal levels, not per entry
-    for (int j = 0; j < per; j++) {
-      const bool tie = (tiem >> j) & 1u;
-      const bool keep = ((surem >> j) & 1u) || (tie && tseen < need);
-      tseen += tie ? 1 : 0;
-      if (keep) {
-        const RawKey rk = in[i0 + j];
-        if (pos < cap_sel) out[pos] = rk;
-        if (rk.level_index != run_level) {
-          if (run) atomicAdd(&lc[run_level], run);
-          run_level = rk.level_index; run = 0;
-        }
-        run++;
-        pos++;
+    static_assert(sizeof(RawKey) == 32 && offsetof(RawKey, level_index) == 0, "RawKey as two uint4");
+    // four entries per trip: the kept ones are loaded with independent loads before any of them is stored (one
+    // memory round trip per trip instead of one per kept entry: with a single workgroup per image the loop is
+    // latency-bound, and it is on the critical path of a single-image run)
+    for (int jb = 0; jb < per; jb += 4) {
+#define HESS_TK_LOAD(U)                                                                                      \
+      const int j##U = jb + U;                                                                               \
+      const bool tie##U = j##U < per && ((tiem >> j##U) & 1u);                                               \
+      const bool kp##U = j##U < per && (((surem >> j##U) & 1u) || (tie##U && tseen < need));                 \
+      tseen += tie##U ? 1 : 0;                                                                               \
+      const uint4* src##U = reinterpret_cast<const uint4*>(in + (kp##U ? i0 + j##U : 0)); /* always load */  \
+      const uint4 ra##U = src##U[0], rb##U = src##U[1]; /* a RawKey is two 16-byte pieces */
+#define HESS_TK_STORE(U)                                                     \
+      if (kp##U) {                                                           \
+        if (pos < cap_sel) {                                                 \
+          uint4* dst = reinterpret_cast<uint4*>(out + pos);                  \
+          dst[0] = ra##U;                                                    \
+          dst[1] = rb##U;                                                    \
+        }                                                                    \
+        const int lvl = (int)ra##U.x; /* RawKey::level_index */              \
+        if (lvl != run_level) {                                              \
+          if (run) atomicAdd(&lc[run_level], run);                           \
+          run_level = lvl; run = 0;                                          \
+        }                                                                    \
+        run++;                                                               \
+        pos++;                                                               \
       }
+      HESS_TK_LOAD(0) HESS_TK_LOAD(1) HESS_TK_LOAD(2) HESS_TK_LOAD(3)
+      HESS_TK_STORE(0) HESS_TK_STORE(1) HESS_TK_STORE(2) HESS_TK_STORE(3)
+#undef HESS_TK_LOAD
+#undef HESS_TK_STORE
     }
     if (run) atomicAdd(&lc[run_level], run);
     __syncthreads();
@@ -1023,10 +1051,11 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 }
 
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch) {
+                          int batch, void* zero, size_t zero_bytes) {
   int blocks = 0;
   for (int o = 0; o < g.noct; o++) blocks += ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
-  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm);
+  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm,
+                     reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16));
 }
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

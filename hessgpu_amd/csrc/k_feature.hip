@@ -519,7 +519,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const float* const rdbin = rows + sub * DC_BIN_PITCH + mycell * 4;  // + 4*DC_BIN_PITCH*k: bins sub, sub+4, sub+8
   const uint32_t theta_end_bits = dp.dynamic_indexing ? 0x41000001u : 0x41000000u;  // 8.0f, or the next float (admits theta == 8)
 
-  for (int m = ffirst + blockIdx.x * 4 + wv; m < ffirst + ftotal; m += nwaves) {
+  // Features are taken from the END of the list backwards: the list is ordered by (octave, level), most features
+  // belong to octave 0, and within an octave the footprint grows with the level, so the launch's last wavefronts --
+  // its tail -- get the smallest features (octave 0, level 1) instead of a mixture.
+  for (int mw = blockIdx.x * 4 + wv; mw < ftotal; mw += nwaves) {
+    const int m = ffirst + ftotal - 1 - mw;
     const int src = fsrc[(long long)b * cap_feat + m];
     const int i = src >> 2, k = src & 3;
     const int oidx = m - ffirst;

@@ -264,6 +264,7 @@ void SiftGPU::PrintUsage() {
 
 void SiftGPU::SetVerbose(int verbose) {  // SiftGPU.cpp:433-464
   Impl* im = I(_pyramid);
+  const int before = (im->verbose ? 1 : 0) | (im->timingS ? 2 : 0);
   im->timingO = (verbose > 2);
   im->timingL = (verbose > 3);
   if (verbose == -1) {
@@ -276,6 +277,8 @@ void SiftGPU::SetVerbose(int verbose) {  // SiftGPU.cpp:433-464
     im->verbose = (verbose > 0);
     im->timingS = (verbose > 1);
   }
+  // messages / stage timers are properties of the device context (hess_params.verbose): rebuilt on the next run
+  if (((im->verbose ? 1 : 0) | (im->timingS ? 2 : 0)) != before) im->dirty = true;
 }
 
 void SiftGPU::ParseParam(int argc, char** argv) {  // SiftGPU.cpp:855-1380
@@ -419,7 +422,7 @@ void SiftGPU::InitSiftGPU() {
   p.sigman = _sigman;
   p.dog_threshold = _dog_threshold;
   p.edge_threshold = _edge_threshold;
-  p.verbose = im->verbose;
+  p.verbose = (im->verbose ? 1 : 0) | (im->timingS ? 2 : 0);  // messages | stage timers (hess_abi.h)
   drop_context(im);  // (results and pixels of the last run are kept in the instance)
   im->ctx = hess_create(im->device, &p);
   im->p = p;

@@ -86,7 +86,9 @@ typedef struct hess_params {
   int32_t feature_count_threshold; /* -tc* / -topk value (<=0 = off)                          */
   int32_t tex_max_dim;          /* -maxd (0=default 3200)                                     */
   int32_t auto_downscale;       /* -ads                                                       */
-  int32_t verbose;              /* 0 silent                                                   */
+  int32_t verbose;              /* bit 0: messages on stderr; bit 1: stage timers (hess_timing entries 2..10; the
+                                   reference's _timingS, SiftGPU.cpp:433-464).  0 = silent, total time only: the
+                                   events between stages cost about 6 us each on the device                  */
   int32_t dynamic_indexing;     /* -di  descriptor bins indexed dynamically (GlobalUtil.cpp:108,
                                    ProgramCU.cu:1755-1771): a sample whose bin coordinate rounds up to
                                    exactly 8.0 is then added to bin 8 (folded into bin 0), not dropped */

@@ -222,9 +222,10 @@ def test_parity_input_formats(gpu_ctx_factory, dtype, fmt):
     _assert_same_features(gk, gd, ok, od, dtype)
 
 
-@pytest.mark.parametrize("w,h", [(251, 50), (124, 24), (125, 25), (372, 73), (1000, 97), (324, 223), (652, 210)])
+@pytest.mark.parametrize("w,h", [(251, 50), (124, 24), (125, 25), (372, 73), (1000, 97), (324, 223), (652, 210),
+                                 (128, 24), (132, 25), (256, 48), (260, 49), (516, 27)])
 def test_parity_noise_ragged(gpu_ctx_factory, w, h):
-    """Dense extrema on sizes that straddle the extrema scan's strip (124 columns) and segment
+    """Dense extrema on sizes that straddle the extrema scan's strip (128 columns; 124 until round 3) and segment
     (24 rows) boundaries; a low threshold keeps the candidate queues of the scan full.  The last two sizes walk the
     octave widths 324, 164, 84, 40 and 652, 328, 164, 84: a next octave wider than half of the previous one (width
     aligned up: its last columns repeat the source's last column) and one narrower (84 -> 40: widths halve

@@ -24,7 +24,16 @@ def test_runsift_rgb_matches_oracle():
     ok, od = o.fetch(0)
     assert k.tobytes() == ok.tobytes() and np.array_equal(d.view(np.uint32), od.view(np.uint32))
     t = s.timing()
-    assert t[11] > 0 and t[2] > 0  # TIMINGS_TOTAL, TIMINGS_BUILD_PYRAMID
+    assert t[11] > 0 and t[2] == 0  # TIMINGS_TOTAL; the wrapper passes -v 0: no stage timers (no events between the stages)
+    s.close()
+    # -v 2 and more (SiftGPU.cpp:433-464: _timingS): stage times in _timing[2..10], same features
+    s = siftgpu_lib.SiftGPU(["-v", "2"])
+    assert s.create_context() == 2 and s.run(img, siftgpu_lib.GL_RGB, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    k2, d2 = s.features()
+    assert k2.tobytes() == ok.tobytes() and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    t = s.timing()
+    assert t[11] > 0 and t[2] > 0 and t[3] > 0 and t[8] > 0  # total, pyramid, detection, descriptors
+    assert abs(sum(t[i] for i in (2, 3, 4, 5, 6, 8, 10)) + t[0] - t[11]) < 0.05 * t[11] + 0.05
     s.close()
 
 
