@@ -332,10 +332,12 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if (p.first_octave > 0) { ds = p.first_octave; ws = width >> ds; hs = height >> ds; }
   else if (p.first_octave < 0) { ds = p.first_octave; ws = (width & ~3) << (-ds); hs = height << (-ds); }  // PyramidCU.cpp:120-138
   if (ws > p.tex_max_dim || hs > p.tex_max_dim) {
-    if (!p.auto_downscale || ds < 0) {
+    if (!p.auto_downscale) {
       set_err(c, "image %dx%d exceeds max dimension %d (use -ads or -maxd)", ws, hs, p.tex_max_dim);
       return HESS_ERR_TOO_BIG;
     }
+    // _octave_min++ until it fits (PyramidCU.cpp:154-166): an up-sampled first octave is up-sampled less, then not at
+    // all, then decimated -- the same loop whatever the sign of the first octave
     do { ds++; ws >>= 1; hs >>= 1; } while (ws > p.tex_max_dim || hs > p.tex_max_dim);
   }
   ws &= ~3;  // TruncateWidthCU
@@ -406,7 +408,10 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->gauss, (size_t)lvl * 4))) return rc;
   if ((rc = ensure(c, c->deth, (size_t)lvl * 4))) return rc;
   if ((rc = ensure(c, c->got, (size_t)gt * 8))) return rc;
-  if ((rc = ensure(c, c->input_f32, (size_t)B * ws * hs * 4))) return rc;
+  {
+    const int up = ds < 0 ? -ds : 0;  // the converted input is held at its own size; the up-sampled copy in `upsampled`
+    if ((rc = ensure(c, c->input_f32, (size_t)B * (ws >> up) * (hs >> up) * 4))) return rc;
+  }
   if (ds < 0 && (rc = ensure(c, c->upsampled, (size_t)B * ws * hs * 4))) return rc;
   {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1149,12 +1154,12 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   bool reserved_nonzero = false;
   for (int r : c->p.reserved) reserved_nonzero = reserved_nonzero || r != 0;
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
-      c->p.first_octave < -3 ||  // "can't upsample by more than 8", PyramidCU.cpp:131-132
       reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;
   }
+  if (c->p.first_octave < -3) c->p.first_octave = -3;  // "can't upsample by more than 8": clamped, PyramidCU.cpp:131-132
   c->device = device;
   resolve(c);
   memset(c->timing, 0, sizeof(c->timing));

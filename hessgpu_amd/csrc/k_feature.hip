@@ -405,8 +405,12 @@ __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams 
 constexpr int DC_BINS = 12;
 constexpr int DC_BIN_PITCH = 80;
 constexpr int DC_ROWS = DC_BINS * DC_BIN_PITCH;
-// dynamic LDS requested at launch on top of the static 17 KB: 36 KB per workgroup -> at most 4 workgroups per CU
-constexpr int DC_LDS_PAD_BYTES = 36 * 1024 - 4 * (4 * DC_ROWS + 4 * 128);
+// Dynamic LDS requested at launch on top of the static 17 KB.  Rounds 1-2 padded a workgroup to 36 KB so that at most
+// four fit a CU (the kernel then measured 5-30 % slower at 5-8 wavefronts per SIMD).  With the all-miss skip and the
+// features taken largest first that no longer holds: without padding (five workgroups per CU, the register limit)
+// the launch takes 0.372 ms per 8 images against 0.405 ms with it, same box (profiles/r03_desc_pad.txt), and the
+// unpadded workgroups leave LDS to the kernels of the other contexts.
+constexpr int DC_LDS_PAD_BYTES = 0;
 
 typedef const __attribute__((address_space(1))) char* GlobalBytes;  // byte pointer into global memory (HBM)
 typedef float dfloat2 __attribute__((ext_vector_type(2)));
@@ -445,10 +449,8 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
 //          for the two bins that are touched and `+= 0 * weight` (no change: weights and sums are finite and
 //          non-negative) for the others.  Per bin the additions therefore happen in the reference's order.
 // No sample lists, no compaction: per iteration a lane does two 2-dword LDS stores (set, clear) and three 16-byte loads.
-// Occupancy: four workgroups (= four wavefronts per SIMD) per CU, enforced by the LDS footprint (DC_LDS_PAD_BYTES).
-// The kernel is bound by vector issue, not by latency: before the all-miss skip, builds with 2, 3 and 4 wavefronts
-// per SIMD ran alike and builds with 5, 6 or 8 (fewer registers, or smaller unroll) 5-30 % slower; with the skip
-// 3, 4, 5 and 6 are within 2 % and 8 is 20 % slower, so the register count must not decide it.
+// Occupancy: five workgroups (= five wavefronts per SIMD) per CU by the register count (see DC_LDS_PAD_BYTES for the
+// history: rounds 1-2 held it at four through the LDS footprint).
 // HOST_MIRROR: the packed results are also stored into their pinned host mirrors (dp.hkeys / dp.hdesc); a template
 // parameter so that the two forms carry different names in profiles (alone on the device the mirroring form waits
 // for PCIe).
@@ -768,11 +770,12 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   int blocks = (cap_feat + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
+  const int lds_pad = DC_LDS_PAD_BYTES;
   if (dp.hkeys || dp.hdesc)
-    hipLaunchKernelGGL(descriptor_kernel<true>, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
+    hipLaunchKernelGGL(descriptor_kernel<true>, dim3(blocks, batch), dim3(256), lds_pad, st, g, dp, list, cap_list, recs, fsrc,
                        feat_total, feat_first, img_base, got, keys, desc, cap_feat);
   else
-    hipLaunchKernelGGL(descriptor_kernel<false>, dim3(blocks, batch), dim3(256), DC_LDS_PAD_BYTES, st, g, dp, list, cap_list, recs, fsrc,
+    hipLaunchKernelGGL(descriptor_kernel<false>, dim3(blocks, batch), dim3(256), lds_pad, st, g, dp, list, cap_list, recs, fsrc,
                        feat_total, feat_first, img_base, got, keys, desc, cap_feat);
 }
 

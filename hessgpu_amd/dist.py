@@ -172,6 +172,10 @@ class HostLanding:
         on_gpu = any(k.is_cuda for k in keys_list)
         dim = desc_list[0].shape[1] if desc_list is not None else 0
         nk = sum(k.shape[0] for r, k in enumerate(keys_list) if r != own_rank)
+        if nk == 0:  # nothing from other ranks (a single rank, or empty lists): nothing to wait for or to copy
+            self.keys = [None if r == own_rank else k.cpu() for r, k in enumerate(keys_list)]
+            self.desc = [None if (r == own_rank or desc_list is None) else desc_list[r].cpu() for r in range(len(keys_list))]
+            return self.keys, self.desc
         self._keys = self._buffer(self._keys, nk * KEY_BYTES, on_gpu)
         if dim:
             self._desc = self._buffer(self._desc, nk * dim * 4, on_gpu)

@@ -826,11 +826,11 @@ hess_cpu_ctx* hess_cpu_create(const hess_params* params) {
   if (!c) return NULL;
   if (params) c->p = *params; else hess_cpu_default_params(&c->p);
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > 10 ||
-      c->p.first_octave < -3 || /* "can't upsample by more than 8", PyramidCU.cpp:131-132 */
       HESS_ORACLE_DETECTOR(&c->p) < 0 || HESS_ORACLE_DETECTOR(&c->p) > 2) {
     free(c);
     return NULL;
   }
+  if (c->p.first_octave < -3) c->p.first_octave = -3; /* "can't upsample by more than 8": clamped, PyramidCU.cpp:131-132 */
   resolve_params(c);
   c->threads = 1;
   c->keep = 1;
@@ -884,7 +884,7 @@ static int plan_geometry(hess_cpu_ctx* c, int width, int height) {
                p->tex_max_dim);
       return HESS_ERR_TOO_BIG;
     }
-    if (ds < 0) { snprintf(c->err, sizeof(c->err), "up-sampled image exceeds max dimension"); return HESS_ERR_TOO_BIG; }
+    /* _octave_min++ until it fits, whatever its sign (PyramidCU.cpp:154-166) */
     do { ds++; ws >>= 1; hs >>= 1; } while (ws > p->tex_max_dim || hs > p->tex_max_dim);
   }
   ws &= ~3; /* TruncateWidthCU, GLTexImage.h:127 */

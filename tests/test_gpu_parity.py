@@ -183,6 +183,11 @@ def test_parity_4096_half_topk65536(gpu_ctx_factory):
     dict(dog_level_num=5),
     dict(dog_level_num=6),   # more than 5 levels: LDS-tiled extrema scan instead of the streaming one
     dict(first_octave=1),
+    # an up-sampled first octave above -maxd with -ads: the reference raises _octave_min step by step, whatever its
+    # sign (PyramidCU.cpp:154-166) -- less up-sampling (-2 -> -1), none (-1 -> 0), and -5 is clamped to -3 first
+    dict(first_octave=-2, auto_downscale=1, tex_max_dim=1400),
+    dict(first_octave=-1, auto_downscale=1, tex_max_dim=700),
+    dict(first_octave=-5, auto_downscale=1, tex_max_dim=1400),
     dict(octave_num=2),
     dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=100),
     dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=100000),

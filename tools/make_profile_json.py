@@ -29,9 +29,9 @@ def main():
     gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith("gauss_kernel"))
     traffic["valu_insts_per_image"] = round(gv / (3 * batch), 1)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
-    dk = "descriptor_kernel<true>" if "descriptor_kernel<true>" in rows else "descriptor_kernel"  # the form that mirrors to the host
-    r = rows[dk]
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
+    dk = dd["kernel"].split()[0]  # the form the benched batch size uses: descriptor_kernel<false> (copier delivery) or <true> (host mirror)
+    r = rows[dk]
     feats = dd["features_per_launch"]
     f = lambda k: float(r[k])
     tr = next((p for p in traffic["per_kernel"] if p["kernel"] == dk), None)
