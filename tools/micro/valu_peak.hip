@@ -10,7 +10,7 @@
 //   clock         = wave cycles / wave real time x 100 MHz
 //   Ginst/s       = SIMDs in use x clock / (cyc/inst/SIMD)
 // for 1, 2, 4 wavefronts per SIMD on ONE CU (one workgroup of 256/512/1024 threads) and 1, 2, 4, 8 wavefronts per SIMD on
-// ALL CUs (256 or 512 workgroups; 80 KB of LDS per workgroup caps a CU at two).  Each configuration runs back to back
+// ALL CUs (256 or 512 workgroups, residency fixed by LDS size / the CU's thread limit, see cfgs[]).  Each configuration runs back to back
 // for about half a second before the launch that is read (the clock settles under load).
 // A `rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE` pass over this program gives the counter-derived clock beside it
 // (tools/profile_valu_peak.sh).
@@ -51,7 +51,6 @@ KERNEL(k_fma, "v_fma_f32 %0, %0, %1, %2", threadIdx.x * 0.001f + i + a)
 KERNEL(k_mul, "v_mul_f32 %0, %0, %1", 1.0f + threadIdx.x * 1e-6f + i * 1e-7f)
 KERNEL(k_add, "v_add_f32 %0, %0, %1", threadIdx.x * 0.001f + i + a)
 KERNEL(k_max3, "v_max3_f32 %0, %0, %1, %2", threadIdx.x * 0.001f + i + a)
-KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc", threadIdx.x * 0.001f + i + a)
 KERNEL(k_cvt, "v_cvt_f32_i32 %0, %0", (float)(threadIdx.x + i))
 KERNEL(k_rcp, "v_rcp_f32 %0, %0", 1.0f + threadIdx.x * 0.001f + i)
 KERNEL(k_exp, "v_exp_f32 %0, %0", -0.001f * threadIdx.x - i)
@@ -97,19 +96,23 @@ int main() {
   float* out;
   CHECK(hipMalloc(&st, sizeof(Stamp) * max_waves));
   CHECK(hipMalloc(&out, 1 << 20));
+  // Residency is fixed by the launch itself: 100 KB of LDS lets a CU hold ONE workgroup of the 1-, 2- and 4-wavefront
+  // configurations (256 workgroups = one per CU); the 8-wavefront configuration is two 1024-thread workgroups per CU,
+  // which the 2048-thread limit of a CU caps at exactly two (512 workgroups of 60 KB).  (With 80 KB the first version
+  // of this table let some CUs take two workgroups and others none: stamps and wall time disagreed.)
   const Config cfgs[] = {
       {"one CU, 1 wave/SIMD", 1, 256, 0, 1, false},    {"one CU, 2 waves/SIMD", 1, 512, 0, 2, false},
-      {"one CU, 4 waves/SIMD", 1, 1024, 0, 4, false},  {"all CUs, 1 wave/SIMD", ncu, 256, 80 * 1024, 1, true},
-      {"all CUs, 2 waves/SIMD", ncu, 512, 80 * 1024, 2, true}, {"all CUs, 4 waves/SIMD", ncu, 1024, 80 * 1024, 4, true},
-      {"all CUs, 8 waves/SIMD", 2 * ncu, 1024, 64 * 1024, 8, true},
+      {"one CU, 4 waves/SIMD", 1, 1024, 0, 4, false},  {"all CUs, 1 wave/SIMD", ncu, 256, 100 * 1024, 1, true},
+      {"all CUs, 2 waves/SIMD", ncu, 512, 100 * 1024, 2, true}, {"all CUs, 4 waves/SIMD", ncu, 1024, 100 * 1024, 4, true},
+      {"all CUs, 8 waves/SIMD", 2 * ncu, 1024, 60 * 1024, 8, true},
   };
   struct K { const char* name; Kern fn; int per_iter; } kernels[] = {
       {"v_fma_f32", k_fma, 64},   {"v_mul_f32", k_mul, 64},         {"v_add_f32", k_add, 64},
-      {"v_max3_f32", k_max3, 64}, {"v_cndmask_b32", k_cndmask, 64}, {"v_cvt_f32_i32", k_cvt, 64},
+      {"v_max3_f32", k_max3, 64}, {"v_cvt_f32_i32", k_cvt, 64},
       {"v_pk_fma_f32", k_pkfma, 64}, {"v_rcp_f32", k_rcp, 64},      {"v_exp_f32", k_exp, 64},
       {"v_mov_b32_dpp", k_dppmov, 64},
   };
-  for (auto& k : kernels) CHECK(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  for (auto& k : kernels) CHECK(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   printf("# MI355X vector-ALU issue: cycles per wave64 instruction and SIMD, clock held, sustained rate (CUs: %d)\n", ncu);
   printf("%-16s %-24s %10s %10s %12s %14s %14s\n", "instruction", "configuration", "cyc/inst", "clock GHz", "Ginst/s", "chip-equiv",
          "wall Ginst/s");
