@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")
     ap.add_argument("--no-api-leg", action="store_true", help="skip the libsiftgpu.so (RunSIFT + GetFeatureVector) legs")
     ap.add_argument("--no-configs4", action="store_true", help="skip the 4096x4096 leg (BASELINE.json configs[4])")
-    ap.add_argument("--api-threads", type=int, default=4, help="SiftGPU instances (host threads) of the multi-instance leg")
+    ap.add_argument("--api-threads", type=int, default=8, help="SiftGPU instances (host threads) of the multi-instance leg")
     ap.add_argument("--gather-dest", choices=("host", "hbm"), default="host",
                     help="N > 1: where the gathered feature lists end on rank 0 (host = pinned host memory, like N = 1)")
     ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "

@@ -30,6 +30,7 @@
 //   stage 3  vertical pass LDS->HBM: a thread produces 4 rows x 2 columns (ds_read_b64, 8-byte
 //            coalesced stores, 512 contiguous bytes per wavefront).
 // Per output the taps are accumulated in the reference's order: v = 0; v = fma(x_i, k_i, v), i=0..FW-1.
+#include <cstdlib>
 #include <cstring>
 
 #include "hess_dev.h"
