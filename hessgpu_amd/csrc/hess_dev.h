@@ -162,9 +162,11 @@ void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& d
 
 // Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
 // the lower list index, order preserved.  sel may alias nothing; when total < K the list is copied.
+// scratch: topk_scratch_bytes(cap_raw, batch) bytes of device memory (chunk counts, cut bins).
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total,
                  int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count,
-                 int cap_sel, int batch);
+                 int cap_sel, int batch, void* scratch);
+size_t topk_scratch_bytes(int cap_raw, int batch);
 
 // Orientation (ComputeOrientation_Kernel, ProgramCU.cu:1221-1605): one wavefront per keypoint.
 void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,

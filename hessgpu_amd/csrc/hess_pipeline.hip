@@ -139,7 +139,7 @@ struct hess_ctx {
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
   DevBuf gauss, deth, got, input_f32, upsampled, stage, rowoff, level_count, raw_total, raw, sel,
-      sel_total, sel_level_count, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
+      sel_total, sel_level_count, tk_scratch, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
   // Everything the detection stages expect zeroed lives in one allocation and is cleared by one fill per batch:
   // overflow flags, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
   DevBuf zeroed;
@@ -433,6 +433,7 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
   if (c->use_topk) {
     if ((rc = ensure(c, c->sel, (size_t)B * cap_sel * sizeof(RawKey)))) return rc;
+    if ((rc = ensure(c, c->tk_scratch, topk_scratch_bytes(cap_raw, B)))) return rc;
   }
   if ((rc = ensure(c, c->recs, (size_t)B * cap_sel * sizeof(FRec)))) return rc;
   if ((rc = ensure(c, c->ocount, (size_t)B * cap_sel * 4))) return rc;
@@ -650,7 +651,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_TOPK, 0.0);
     launch_topk(st, g, p.feature_count_threshold, (const RawKey*)c->raw.p, (const int*)c->raw_total.p, c->cap_raw,
                 (unsigned*)c->hist.p, (RawKey*)c->sel.p, (int*)c->sel_total.p, (int*)c->sel_level_count.p,
-                c->cap_sel, batch);
+                c->cap_sel, batch, c->tk_scratch.p);
     list = (const RawKey*)c->sel.p;
     list_total = (const int*)c->sel_total.p;
     cap_list = c->cap_sel;
@@ -1198,7 +1199,7 @@ void hess_destroy(hess_ctx* c) {
   stager_stop(c->sg);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
-                    &c->sel_level_count, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
+                    &c->sel_level_count, &c->tk_scratch, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
   for (DevBuf* b : bufs) release(*b);
   release(c->h_keys, true);

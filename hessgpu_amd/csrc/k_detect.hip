@@ -893,125 +893,168 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
 
 // =============================== top-K =======================================================
 
-__global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const RawKey* raw, const int* raw_total,
-                                                           int cap_raw, const unsigned* hist, RawKey* sel,
-                                                           int* sel_total, int* sel_level_count, int cap_sel) {
+// Top-K in two wide launches (rounds 1-2: one 1024-thread workgroup per image did the whole selection -- 33 us on the
+// critical path of a single 1080p image, 0.24 ms for a 4096^2 image with 2.6e5 detections).  The list is cut into chunks of
+// TK_CHUNK entries, one workgroup each:
+//   topk_count_kernel    finds the cut bin and the number of tied entries to keep from the 15-bit histogram (every
+//                        workgroup with work for itself: 128 KB from L2), classifies its chunk from the keys alone and
+//                        posts (sure keeps, ties) of the chunk; the image's first workgroup also posts cut / need and
+//                        clears the per-level counts;
+//   topk_scatter_kernel  sums the counts of the chunks before its own (list order = chunk order), classifies again, one
+//                        workgroup scan gives every thread its tie rank and output position -- of the first T ties
+//                        min(T, need) are kept -- and the kept entries are copied in order.
+// Same result as before: the K largest abs(half(response)), ties at the cut to the lower list index, list order kept.
+constexpr int TK_PER = 4, TK_CHUNK = 1024 * TK_PER;
+
+struct TopkChunk { int sure, ties; };
+
+// cut bin and number of ties to keep, by all 1024 threads of a workgroup; n >= K.  Result in s_cut / s_need (LDS).
+__device__ __forceinline__ void topk_find_cut(const unsigned* h, int K, int* lds, int* s_cut, int* s_need) {
+  const int tid = threadIdx.x;
+  // thread t owns bins [32t, 32t+32); threads are scanned from the high end: thread r = 1023 - tid loads the bins of scan
+  // position tid, so that the thread which finds the cut inside its position walks values it already holds
+  const int owner = 1023 - tid;
+  int vals[32];
+  {
+    const uint4* hv = reinterpret_cast<const uint4*>(h + owner * 32);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint4 v = hv[q];
+      vals[4 * q] = (int)v.x; vals[4 * q + 1] = (int)v.y; vals[4 * q + 2] = (int)v.z; vals[4 * q + 3] = (int)v.w;
+    }
+  }
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < 32; k++) mine += vals[k];
+  int e, e2, tot, tot2;  // suffix sum over the bins = exclusive prefix over the reversed order
+  block_scan2(mine, 0, &e, &e2, &tot, &tot2, lds);
+  const int above = e, incl = e + mine;  // e = count in strictly higher bins
+  if (above < K && incl >= K) {
+    int acc = above;
+    bool found = false;
+#pragma unroll
+    for (int k = 31; k >= 0; k--) {
+      const int c = vals[k];
+      if (!found && acc + c >= K) { *s_cut = owner * 32 + k; *s_need = K - acc; found = true; }
+      acc += c;
+    }
+  }
+  __syncthreads();
+}
+
+// keys of this thread's TK_PER consecutive entries -> bit masks (sure keep, tie at the cut)
+__device__ __forceinline__ void topk_classify(const RawKey* in, int i0, int n, int cut, uint32_t* surem, uint32_t* tiem) {
+  uint32_t pk[TK_PER];
+#pragma unroll
+  for (int u = 0; u < TK_PER; u++) pk[u] = in[max(min(i0 + u, n - 1), 0)].packed;  // (an empty list reads entry 0: never used)
+  uint32_t sm = 0, tm = 0;
+#pragma unroll
+  for (int u = 0; u < TK_PER; u++) {
+    if (i0 + u < n) {
+      const int key = (int)((pk[u] >> 16) & 0x7fffu);
+      if (cut < 0 || key > cut) sm |= 1u << u;
+      else if (key == cut) tm |= 1u << u;
+    }
+  }
+  *surem = sm; *tiem = tm;
+}
+
+__global__ __launch_bounds__(1024) void topk_count_kernel(Geom g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
+                                                          const unsigned* hist, TopkChunk* chunks, int* cutbuf,
+                                                          int* sel_level_count, int nchunk) {
+  __shared__ int lds[64];
+  __shared__ int s_cut, s_need;
+  const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+  const int n = raw_total[b];
+  if (ck * TK_CHUNK >= n && ck != 0) return;  // (workgroup-uniform) nothing in this chunk
+  if (tid == 0) { s_cut = -1; s_need = 0; }
+  __syncthreads();
+  if (n >= K) topk_find_cut(hist + (long long)b * kHistBins, K, lds, &s_cut, &s_need);  // SelectTopK is skipped below K detections
+  const int cut = s_cut, need = s_need;
+  if (ck == 0) {
+    if (tid == 0) { cutbuf[2 * b] = cut; cutbuf[2 * b + 1] = need; }
+    for (int i = tid; i < g.nlev; i += 1024) sel_level_count[b * g.nlev + i] = 0;
+  }
+  uint32_t surem, tiem;
+  topk_classify(raw + (long long)b * cap_raw, ck * TK_CHUNK + tid * TK_PER, n, cut, &surem, &tiem);
+  int etie, esure, ttie, tsure;
+  block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
+  if (tid == 0) { chunks[(long long)b * nchunk + ck].sure = tsure; chunks[(long long)b * nchunk + ck].ties = ttie; }
+}
+
+__global__ __launch_bounds__(1024) void topk_scatter_kernel(Geom g, const RawKey* raw, const int* raw_total, int cap_raw,
+                                                            const TopkChunk* chunks, const int* cutbuf, RawKey* sel,
+                                                            int* sel_total, int* sel_level_count, int cap_sel, int nchunk) {
   __shared__ int lds[64];
   __shared__ int lc[kMaxOct * kMaxDog];
-  __shared__ int s_cut, s_need, s_ties, s_kept;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_sure0, s_ties0, s_sure_all, s_ties_all;
+  const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
   const int n = raw_total[b];
+  if (ck * TK_CHUNK >= n && ck != 0) return;  // (workgroup-uniform)
   const RawKey* in = raw + (long long)b * cap_raw;
   RawKey* out = sel + (long long)b * cap_sel;
+  const int cut = cutbuf[2 * b], need = cutbuf[2 * b + 1];
   for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
-  if (tid == 0) { s_cut = -1; s_need = 0; s_ties = 0; s_kept = 0; }
-  __syncthreads();
-  if (n >= K) {
-    // thread t owns bins [32t, 32t+32); threads are scanned from the high end
-    const unsigned* h = hist + (long long)b * kHistBins;
-    // Thread r = 1023 - tid loads the bins of scan position tid, so that the thread which finds the cut inside its
-    // position walks values it already holds (the walk used to re-read its 32 bins one dependent load at a time).
-    const int owner = 1023 - tid;
-    int vals[32];
-    {
-      const uint4* hv = reinterpret_cast<const uint4*>(h + owner * 32);
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint4 v = hv[q];
-        vals[4 * q] = (int)v.x; vals[4 * q + 1] = (int)v.y; vals[4 * q + 2] = (int)v.z; vals[4 * q + 3] = (int)v.w;
-      }
+  // counts of the chunks before this one (and, for the image's first workgroup, of all of them: the kept total)
+  const int used = (n + TK_CHUNK - 1) / TK_CHUNK;
+  {
+    int ps = 0, pt = 0, as = 0, at = 0;
+    for (int k = tid; k < used; k += 1024) {
+      const TopkChunk c = chunks[(long long)b * nchunk + k];
+      if (k < ck) { ps += c.sure; pt += c.ties; }
+      as += c.sure; at += c.ties;
     }
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k++) mine += vals[k];
-    // suffix sum over the bins = exclusive prefix over the reversed order
-    int e, e2, tot, tot2;
-    block_scan2(mine, 0, &e, &e2, &tot, &tot2, lds);
-    const int above = e, incl = e + mine;  // e = count in strictly higher bins
-    if (above < K && incl >= K) {
-      int acc = above;
-      bool found = false;
-#pragma unroll
-      for (int k = 31; k >= 0; k--) {
-        const int c = vals[k];
-        if (!found && acc + c >= K) { s_cut = owner * 32 + k; s_need = K - acc; found = true; }
-        acc += c;
-      }
-    }
+    int e0, e1, t0, t1, t2, t3;
+    block_scan2(ps, pt, &e0, &e1, &t0, &t1, lds);
+    __syncthreads();
+    block_scan2(as, at, &e0, &e1, &t2, &t3, lds);
+    if (tid == 0) { s_sure0 = t0; s_ties0 = t1; s_sure_all = t2; s_ties_all = t3; }
     __syncthreads();
   }
-  const int cut = s_cut, need = s_need;
-  // ordered compaction: keep key > cut, and the first `need` entries with key == cut.  A thread takes up to 32
-  // consecutive entries (list order = thread order, then entry order): it classifies them from their keys alone,
-  // one workgroup scan of (ties, sure keeps) gives every thread its tie rank and output position -- of the first T
-  // ties min(T, need) are kept -- and only the kept entries are read in full and written.  A 16 k list is one pass.
-  for (int base = 0; base < n; base += 1024 * 32) {
-    const int left = n - base;
-    const int per = left >= 1024 * 32 ? 32 : (left + 1023) >> 10;  // uniform over the workgroup
-    const int i0 = base + tid * per;
-    uint32_t surem = 0, tiem = 0;
-    for (int j0 = 0; j0 < per; j0 += 8) {  // eight keys per trip: independent loads
-      uint32_t pk[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) pk[u] = in[min(i0 + j0 + u, n - 1)].packed;
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = j0 + u;
-        if (j < per && i0 + j < n) {
-          const int key = (int)((pk[u] >> 16) & 0x7fffu);
-          if (cut < 0 || key > cut) surem |= 1u << j;
-          else if (key == cut) tiem |= 1u << j;
-        }
-      }
-    }
-    int etie, esure, ttie, tsure;
-    block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
-    const int ties0 = s_ties, kept0 = s_kept;
-    int tseen = ties0 + etie;                                  // ties before this thread's entries
-    int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
-    int run_level = -1, run = 0;  // kept entries per level: one LDS atomic per run of equal levels, not per entry
-    static_assert(sizeof(RawKey) == 32 && offsetof(RawKey, level_index) == 0, "RawKey as two uint4");
-    // four entries per trip: the kept ones are loaded with independent loads before any of them is stored (one
-    // memory round trip per trip instead of one per kept entry: with a single workgroup per image the loop is
-    // latency-bound, and it is on the critical path of a single-image run)
-    for (int jb = 0; jb < per; jb += 4) {
-#define HESS_TK_LOAD(U)                                                                                      \
-      const int j##U = jb + U;                                                                               \
-      const bool tie##U = j##U < per && ((tiem >> j##U) & 1u);                                               \
-      const bool kp##U = j##U < per && (((surem >> j##U) & 1u) || (tie##U && tseen < need));                 \
-      tseen += tie##U ? 1 : 0;                                                                               \
-      const uint4* src##U = reinterpret_cast<const uint4*>(in + (kp##U ? i0 + j##U : 0)); /* always load */  \
-      const uint4 ra##U = src##U[0], rb##U = src##U[1]; /* a RawKey is two 16-byte pieces */
+  const int ties0 = s_ties0, kept0 = s_sure0 + min(ties0, need);
+  if (ck == 0 && tid == 0) {
+    const int kept = s_sure_all + min(s_ties_all, need);
+    sel_total[b] = kept < cap_sel ? kept : cap_sel;
+  }
+  const int i0 = ck * TK_CHUNK + tid * TK_PER;
+  uint32_t surem, tiem;
+  topk_classify(in, i0, n, cut, &surem, &tiem);
+  int etie, esure, ttie, tsure;
+  block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
+  int tseen = ties0 + etie;                                  // ties before this thread's entries
+  int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
+  int run_level = -1, run = 0;  // kept entries per level: one LDS atomic per run of equal levels, not per entry
+  // the kept entries are loaded with independent loads before any of them is stored (one memory round trip)
+#define HESS_TK_LOAD(U)                                                                                    \
+  const bool tie##U = (tiem >> U) & 1u;                                                                    \
+  const bool kp##U = ((surem >> U) & 1u) || (tie##U && tseen < need);                                      \
+  tseen += tie##U ? 1 : 0;                                                                                 \
+  const uint4* src##U = reinterpret_cast<const uint4*>(in + (kp##U ? i0 + U : 0)); /* always load */       \
+  const uint4 ra##U = src##U[0], rb##U = src##U[1]; /* a RawKey is two 16-byte pieces */
 #define HESS_TK_STORE(U)                                                     \
-      if (kp##U) {                                                           \
-        if (pos < cap_sel) {                                                 \
-          uint4* dst = reinterpret_cast<uint4*>(out + pos);                  \
-          dst[0] = ra##U;                                                    \
-          dst[1] = rb##U;                                                    \
-        }                                                                    \
-        const int lvl = (int)ra##U.x; /* RawKey::level_index */              \
-        if (lvl != run_level) {                                              \
-          if (run) atomicAdd(&lc[run_level], run);                           \
-          run_level = lvl; run = 0;                                          \
-        }                                                                    \
-        run++;                                                               \
-        pos++;                                                               \
-      }
-      HESS_TK_LOAD(0) HESS_TK_LOAD(1) HESS_TK_LOAD(2) HESS_TK_LOAD(3)
-      HESS_TK_STORE(0) HESS_TK_STORE(1) HESS_TK_STORE(2) HESS_TK_STORE(3)
+  if (kp##U) {                                                               \
+    if (pos < cap_sel) {                                                     \
+      uint4* dst = reinterpret_cast<uint4*>(out + pos);                      \
+      dst[0] = ra##U;                                                        \
+      dst[1] = rb##U;                                                        \
+    }                                                                        \
+    const int lvl = (int)ra##U.x; /* RawKey::level_index */                  \
+    if (lvl != run_level) {                                                  \
+      if (run) atomicAdd(&lc[run_level], run);                               \
+      run_level = lvl; run = 0;                                              \
+    }                                                                        \
+    run++;                                                                   \
+    pos++;                                                                   \
+  }
+  static_assert(TK_PER == 4 && sizeof(RawKey) == 32 && offsetof(RawKey, level_index) == 0, "RawKey as two uint4, four per thread");
+  HESS_TK_LOAD(0) HESS_TK_LOAD(1) HESS_TK_LOAD(2) HESS_TK_LOAD(3)
+  HESS_TK_STORE(0) HESS_TK_STORE(1) HESS_TK_STORE(2) HESS_TK_STORE(3)
 #undef HESS_TK_LOAD
 #undef HESS_TK_STORE
-    }
-    if (run) atomicAdd(&lc[run_level], run);
-    __syncthreads();
-    if (tid == 0) {
-      s_ties = ties0 + ttie;
-      s_kept = kept0 + tsure + (min(ties0 + ttie, need) - min(ties0, need));
-    }
-    __syncthreads();
-  }
-  if (tid == 0) sel_total[b] = s_kept < cap_sel ? s_kept : cap_sel;
-  for (int i = tid; i < g.nlev; i += 1024) sel_level_count[b * g.nlev + i] = lc[i];
+  if (run) atomicAdd(&lc[run_level], run);
+  __syncthreads();
+  for (int i = tid; i < g.nlev; i += 1024)
+    if (lc[i]) atomicAdd(&sel_level_count[b * g.nlev + i], lc[i]);
 }
 
 // =============================== math probe (parity tests) ===================================
@@ -1100,11 +1143,23 @@ void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& d
                      rowmask, rowoff, raw_total, raw, cap_raw, hist, topk);
 }
 
+int topk_chunks(int cap_raw) { return (cap_raw + TK_CHUNK - 1) / TK_CHUNK; }
+
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
-                 unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch) {
-  // hist: zeroed by the batch's fill, counted by extrema_scatter_kernel
-  hipLaunchKernelGGL(topk_select_kernel, dim3(batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist, sel,
-                     sel_total, sel_level_count, cap_sel);
+                 unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch,
+                 void* scratch) {
+  // hist: zeroed with the batch's detection buffers, counted by extrema_scatter_kernel.  scratch: topk_scratch_bytes()
+  const int nchunk = topk_chunks(cap_raw);
+  int* cutbuf = reinterpret_cast<int*>(scratch);
+  TopkChunk* chunks = reinterpret_cast<TopkChunk*>(cutbuf + 2 * batch);
+  hipLaunchKernelGGL(topk_count_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist,
+                     chunks, cutbuf, sel_level_count, nchunk);
+  hipLaunchKernelGGL(topk_scatter_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, raw, raw_total, cap_raw, chunks,
+                     cutbuf, sel, sel_total, sel_level_count, cap_sel, nchunk);
+}
+
+size_t topk_scratch_bytes(int cap_raw, int batch) {
+  return (size_t)batch * (2 * sizeof(int) + (size_t)topk_chunks(cap_raw) * sizeof(TopkChunk));
 }
 
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n) {

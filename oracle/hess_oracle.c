@@ -176,6 +176,20 @@ static float initial_smooth_sigma(const hess_cpu_ctx* c, int octave_min) {
 }
 
 /* ProgramCU::CreateFilterKernel, ProgramCU.cu:423-453 (host code; libm expf). */
+/* Sample-window clamps at the image border.  The CUDA path (the product's rule, and the unpacked GLSL shaders' too:
+ * ProgramCU.cu:1324-1332,1723-1731, ProgramGLSL.cpp:1242-1244,1617-1619) keeps sample centres in [1.5, dim-1.5].
+ * HESS_ORACLE_BORDER(p) == 1 (analysis only, tests/test_reference_fixture.py) is the rule of the PACKED GLSL shaders
+ * (ProgramGLSL.cpp:1883-1885,2579-2581: the box is clamped to [2, dim-3] and then widened to whole 2x2 texels), the
+ * default backend of the SiftGPU versions that could have written doc/evaluation/box.siftgpu. */
+static inline float border_lo(const hess_cpu_ctx* c, float v) {
+  if (HESS_ORACLE_BORDER(&c->p) == 1) return 2.0f * floorf(fmaxf(v, 2.0f) * 0.5f) + 0.5f;
+  return fmaxf(1.5f, floorf(v) + 0.5f);
+}
+static inline float border_hi(const hess_cpu_ctx* c, float v, int dim) {
+  if (HESS_ORACLE_BORDER(&c->p) == 1) return 2.0f * floorf(fminf(v, (float)dim - 3.0f) * 0.5f) + 1.5f;
+  return fminf(dim - 1.5f, floorf(v) + 0.5f);
+}
+
 static int create_filter_kernel(const hess_cpu_ctx* c, float sigma, float* kernel) {
   int i, sz = (int)ceil(c->p.filter_width_factor * sigma - 0.5);
   int width = 2 * sz + 1;
@@ -516,10 +530,10 @@ static void compute_orientation(const hess_cpu_ctx* c, const hess_rawkey* rk, co
     float win = fabsf(kz) * sample_factor;
     float dist_threshold = win * win + 0.5f;
     float factor = -0.5f / (gsigma * gsigma);
-    float xmin = fmaxf(1.5f, floorf(kx - win) + 0.5f);
-    float ymin = fmaxf(1.5f, floorf(ky - win) + 0.5f);
-    float xmax = fminf(width - 1.5f, floorf(kx + win) + 0.5f);
-    float ymax = fminf(height - 1.5f, floorf(ky + win) + 0.5f);
+    float xmin = border_lo(c, kx - win);
+    float ymin = border_lo(c, ky - win);
+    float xmax = border_hi(c, kx + win, width);
+    float ymax = border_hi(c, ky + win, height);
     for (int i = 0; i < 36; ++i) vote[i] = 0.0f;
     for (float y = ymin; y <= ymax; y += 1.0f) {
       float dy = y - ky;
@@ -666,10 +680,10 @@ static void compute_orientation_existing(const hess_cpu_ctx* c, frec* rec, const
   float win = fabsf(kz) * (p->orient_gaussian_factor * p->orient_window_factor);
   float dist_threshold = win * win + 0.5f;
   float factor = -0.5f / (gsigma * gsigma);
-  float xmin = fmaxf(1.5f, floorf(kx - win) + 0.5f);
-  float ymin = fmaxf(1.5f, floorf(ky - win) + 0.5f);
-  float xmax = fminf(width - 1.5f, floorf(kx + win) + 0.5f);
-  float ymax = fminf(height - 1.5f, floorf(ky + win) + 0.5f);
+  float xmin = border_lo(c, kx - win);
+  float ymin = border_lo(c, ky - win);
+  float xmax = border_hi(c, kx + win, width);
+  float ymax = border_hi(c, ky + win, height);
   for (int i = 0; i < 36; ++i) vote[i] = 0.0f;
   for (float y = ymin; y <= ymax; y += 1.0f) {
     float dy = y - ky;
@@ -734,10 +748,10 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
     float ptx = fmaf(cspt, offx, -(sspt * offy)) + kx;
     float pty = fmaf(cspt, offy, sspt * offx) + ky;
     float bsz = fabsf(cspt) + fabsf(sspt);
-    float xmin = fmaxf(1.5f, floorf(ptx - bsz) + 0.5f);
-    float ymin = fmaxf(1.5f, floorf(pty - bsz) + 0.5f);
-    float xmax = fminf(width - 1.5f, floorf(ptx + bsz) + 0.5f);
-    float ymax = fminf(height - 1.5f, floorf(pty + bsz) + 0.5f);
+    float xmin = border_lo(c, ptx - bsz);
+    float ymin = border_lo(c, pty - bsz);
+    float xmax = border_hi(c, ptx + bsz, width);
+    float ymax = border_hi(c, pty + bsz, height);
     float des[9];
     for (int i = 0; i < 9; ++i) des[i] = 0.0f;
     for (float y = ymin; y <= ymax; y += 1.0f) {

@@ -41,6 +41,10 @@ typedef struct hess_cpu_ctx hess_cpu_ctx;
  *   1 = difference of Gaussians as the reference compiles without GPU_HESSIAN (config.h:36)
  *   2 = the same with the level sigmas of the version that wrote doc/evaluation/box.siftgpu */
 #define HESS_ORACLE_DETECTOR(p) ((p)->reserved[0])
+/* Analysis switch, reserved word 1 (zero for the product): sample-window clamps at the image border.
+ *   0 = the CUDA path's rule (sample centres in [1.5, dim-1.5]; also the unpacked GLSL shaders')
+ *   1 = the packed GLSL shaders' rule (box clamped to [2, dim-3], widened to whole 2x2 texels) */
+#define HESS_ORACLE_BORDER(p) ((p)->reserved[1])
 
 void hess_cpu_default_params(hess_params* p);
 hess_cpu_ctx* hess_cpu_create(const hess_params* params);

@@ -52,8 +52,10 @@ class OracleSession(Session):
     def __init__(self, threads=1, keep_levels=True, **overrides):
         l = lib()
         detector = overrides.pop("detector", 0)   # the oracle's extension word (oracle/hess_oracle.h), not a product option
+        border = overrides.pop("border", 0)       # analysis switch: 1 = the packed GLSL shaders' border rule
         p = make_params(_fns["default_params"], **overrides)
         p.reserved[0] = detector
+        p.reserved[1] = border
         h = l.hess_cpu_create(C.byref(p))
         super().__init__(_fns, h, p)
         l.hess_cpu_set_threads(h, threads)

@@ -68,6 +68,29 @@ def test_oracle_as_the_dog_build_reproduces_the_file_from_pixels():
     assert (r["owin_margin"] < 0).sum() >= len(r["unmatched"]) - 1    # what is not matched sits at the image border
 
 
+def test_border_keypoints_of_the_file_follow_the_packed_glsl_rule():
+    """The 92 keypoints whose descriptor footprint touches the image border: with the CUDA path's clamp (sample centres in
+    [1.5, dim-1.5], ProgramCU.cu:1723-1731 -- the product's rule) 40 % of them agree with the file, with the clamp of the
+    PACKED GLSL shaders (box clamped to [2, dim-3] and widened to whole 2x2 texels, ProgramGLSL.cpp:2579-2581; an
+    analysis switch of the oracle, never of the product) 85 % do, and the orientations of the cut windows follow.  So the
+    file was written by the packed GLSL backend: its border keypoints cannot pin the CUDA path's border rule, and they are
+    no evidence against it either; the interior ones are the same under both rules."""
+    img, vals = bf.load()
+    res = {}
+    for border in (0, 1):
+        o = OracleSession(threads=8, border=border, **bf.PARAMS)
+        res[border] = bf.analyse(o, img, vals)
+        o.close()
+    it = res[0]["interior"]
+    assert it.sum() == 581 and (~it).sum() == 92
+    for border in (0, 1):
+        assert (res[border]["err"][it] <= 1).all()                       # interior keypoints: the rule does not matter
+    cuda, packed = (res[0]["err"][~it] <= 1).sum(), (res[1]["err"][~it] <= 1).sum()
+    assert cuda <= 45 and packed >= 75, (cuda, packed)
+    cut = ~res[0]["ointerior"]
+    assert (res[1]["dangle"][cut] < bf.HALF_QUANTUM).mean() > (res[0]["dangle"][cut] < bf.HALF_QUANTUM).mean() + 0.2
+
+
 def test_dog_mode_is_refused_by_the_product():
     import ctypes as C
 
