@@ -479,6 +479,12 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
             "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"], 1),
             "launches": g["launches"], "ms_per_step": round(g["ms"] / steps, 4),
         })
+        mix = _profile_value("hbm_mix.json", "one_read_four_writes_gbs")
+        if mix:  # what this chip sustains for a level launch's traffic mix (4 B read, 16 B written per pixel)
+            out[-1]["achievable_for_mix"] = {"peak": mix, "unit": "GB/s", "frac": round(achieved / mix, 4),
+                                             "source": "tools/micro/hbm_mix.hip, one read to four writes (profiles/r03_hbm_mix.txt); "
+                                                       "the octave-0 launches alone run at 0.87-0.97 of it, the 24 latency-bound "
+                                                       "launches of the smaller octaves pull the stage's average down"}
         gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
         if gi:
             rate = gi * images * steps / (g["ms"] * 1e-3) / 1e9
