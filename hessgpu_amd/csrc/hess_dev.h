@@ -52,8 +52,21 @@ struct Geom {
   int NM;               // mask words per image
   int ntiles;           // extrema tiles per image
   int nstream;          // streaming extrema workgroups per image
+  int stream_rows;      // rows per wavefront segment of the streaming extrema scan (a multiple of 3)
   OctGeom o[kMaxOct];
 };
+
+// Segment length of the streaming extrema scan and the workgroup layout that follows from it (four (strip, segment)
+// tasks per workgroup, octaves back to back).  Batches of one or two images take short segments: twice the
+// wavefronts, each half as long -- the scan of a single image is a few hundred wavefronts, latency-bound.
+inline void set_stream_rows(Geom& g, int rows) {
+  g.stream_rows = rows;
+  g.nstream = 0;
+  for (int o = 0; o < g.noct; o++) {
+    g.o[o].stream_base = g.nstream;
+    g.nstream += (g.o[o].strips * ((g.o[o].h + rows - 1) / rows) + 3) / 4;
+  }
+}
 
 struct Taps {
   int fw;               // number of taps (odd, 5..33)
@@ -121,6 +134,22 @@ void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long 
                   long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
                   float* deth_src = nullptr, float* got_src = nullptr, float norm_src = 0.0f,
                   float* decim_dst = nullptr, int decim_w = 0, int decim_h = 0);
+
+// One level launch as data (float source with pitch wa), for launch_gauss_pair.
+struct GaussJob {
+  const float* src;
+  float* dst;
+  int wa, h;
+  Taps taps;
+  float* deth_src;
+  float* got_src;
+  float norm_src;
+  float* decim_dst;
+  int decim_w, decim_h;
+};
+// Two independent level launches in one grid (the top level of an octave and level 1 of the next); false if the pair of
+// tap counts is not instantiated: launch them separately then.
+bool launch_gauss_pair(hipStream_t st, const GaussJob& a, const GaussJob& b, int batch);
 
 // Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,

@@ -374,8 +374,6 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
     og.tile_base = g.ntiles;
     g.ntiles += og.tiles_x * ((og.h + 3) / 4);  // EX_TR rows per extrema tile (k_detect.hip)
     og.strips = (og.wa + kStreamPitch - 1) / kStreamPitch;
-    og.stream_base = g.nstream;  // four (strip, segment) tasks per workgroup
-    g.nstream += (og.strips * ((og.h + kStreamRows - 1) / kStreamRows) + 3) / 4;
     lvl += (long long)c->sch.level_num * B * og.plane;
     gt += (long long)g.dog * B * og.plane;
     rows += g.dog * og.h;
@@ -385,6 +383,7 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   }
   g.NR = rows;
   g.NM = mw;
+  set_stream_rows(g, kStreamRows);
 
   c->use_topk = (p.truncate_method == HESS_TRUNC_TOPK && p.feature_count_threshold > 0);
   c->multi = (p.max_orientation > 1) && !p.fixed_orientation;  // SiftPyramid.cpp:140
@@ -565,6 +564,37 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // The launch that produces the down-sampling level also writes level 0 of the next octave (its even rows and
   // columns): no decimation launches.  (A down-sampling level 0 is nobody's product: separate kernel then.)
   const bool fused_decim = s.level_ds >= 1 && s.level_ds <= s.level_max;
+  // Level l of octave o from level l-1; the same launch emits det-H (+ gradient/theta) of level l-1 from the source
+  // window it stages: 8 B R+W for the blur, 4 B (+8 B) W for the fused planes (+ 4 B per pixel of the next octave's
+  // level 0 when it is the down-sampling level).
+  auto level_job = [&](int o, int l) {
+    const OctGeom& og = g.o[o];
+    const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
+    const bool decim = fused_decim && l == s.level_ds && o + 1 < g.noct;
+    GaussJob j;
+    j.src = plane_ptr(gauss, o, l - 1); j.dst = plane_ptr(gauss, o, l); j.wa = og.wa; j.h = og.h; j.taps = s.taps[l];
+    j.deth_src = plane_ptr(deth, o, l - 1);
+    j.got_src = src_got ? got + 2 * (og.got_off + (long long)(l - 2) * g.B * og.plane) : nullptr;
+    j.norm_src = s.norm[l - 1];
+    j.decim_dst = decim ? plane_ptr(gauss, o + 1, 0) : nullptr;
+    j.decim_w = decim ? g.o[o + 1].wa : 0; j.decim_h = decim ? g.o[o + 1].h : 0;
+    return j;
+  };
+  auto level_bytes = [&](int o, int l) {
+    const OctGeom& og = g.o[o];
+    const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
+    const bool decim = fused_decim && l == s.level_ds && o + 1 < g.noct;
+    return (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)) + (decim ? (double)batch * g.o[o + 1].plane * 4.0 : 0.0);
+  };
+  auto launch_level = [&](const GaussJob& j) {
+    launch_gauss(st, j.src, nullptr, j.wa, (long long)j.wa * j.h, j.dst, j.wa, j.h, batch, j.taps, j.deth_src, j.got_src,
+                 j.norm_src, j.decim_dst, j.decim_w, j.decim_h);
+  };
+  // T(o, l) = 3o + l is the earliest step of level l of octave o (level 0 of octave o+1 is the decimated level_ds of
+  // octave o): the top level of an octave and level 1 of the next are due together and independent, so they share a
+  // launch (launch_gauss_pair) -- one launch fewer per octave in the dependent chain.
+  const bool pair_levels = fused_decim && s.level_ds < s.level_max && s.level_max >= 2 && !getenv("HESS_NO_PAIR");
+  int deferred_o = -1;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
     // image b of level l lives at plane_ptr(.., o, l) + b*plane: a batch is contiguous per level
@@ -585,17 +615,21 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
                         plane_ptr(gauss, o, 0), og.wa, og.h, batch);
     }
     for (int l = 1; l <= s.level_max; l++) {
-      // level l from level l-1; the same launch emits det-H (+ gradient/theta) of level l-1 from the
-      // source window it stages: 8 B R+W for the blur, 4 B (+8 B) W for the fused planes
-      const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
-      const bool decim = fused_decim && l == s.level_ds && o + 1 < g.noct;
-      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)) +
-                                        (decim ? (double)batch * g.o[o + 1].plane * 4.0 : 0.0));
-      launch_gauss(st, plane_ptr(gauss, o, l - 1), nullptr, og.wa, og.plane, plane_ptr(gauss, o, l), og.wa, og.h,
-                   batch, s.taps[l], plane_ptr(deth, o, l - 1),
-                   src_got ? got + 2 * (og.got_off + (long long)(l - 2) * g.B * og.plane) : nullptr, s.norm[l - 1],
-                   decim ? plane_ptr(gauss, o + 1, 0) : nullptr, decim ? g.o[o + 1].wa : 0, decim ? g.o[o + 1].h : 0);
+      if (l == 1 && deferred_o >= 0) {  // the previous octave's top level rides with this octave's level 1
+        const GaussJob ja = level_job(deferred_o, s.level_max), jb = level_job(o, 1);
+        ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max) + level_bytes(o, 1));
+        if (!launch_gauss_pair(st, ja, jb, batch)) { launch_level(ja); launch_level(jb); }
+        deferred_o = -1;
+        continue;
+      }
+      if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
+      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l));
+      launch_level(level_job(o, l));
     }
+  }
+  if (deferred_o >= 0) {  // (cannot happen: the last octave never defers)
+    ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max));
+    launch_level(level_job(deferred_o, s.level_max));
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
@@ -631,7 +665,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     double det_bytes = 0;
     for (int o = 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
-    launch_extrema_mark(st, g, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
+    Geom gx = g;
+    if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);  // one or two images: shorter segments, twice the wavefronts
+    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
   launch_row_scan(st, g, lp, (const int*)c->rowcnt.p, (int*)c->rowoff.p, (int*)c->level_count.p,

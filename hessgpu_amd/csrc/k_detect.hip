@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
 
 // ---- streaming extrema scan (pass 1, default for dog <= 5): registers instead of an LDS tile ----
 // One wavefront marches down a strip of 124 owned columns (lane j holds columns x0-2+2j, x0-1+2j of
-// every det-H level; lanes 0 and 63 only supply the halo column) over SX_ROWS rows.  (Columns per lane =
+// every det-H level; lanes 0 and 63 only supply the halo column) over Geom::stream_rows rows (24; 12 for batches of one or two images).  (Columns per lane =
 // kStreamCols, hess_dev.h: with one column per lane the kernel needs 116 instead of 168 registers and runs four
 // instead of three wavefronts per SIMD, but spends 43 % more instructions per pixel on the neighbour exchange:
 // same time)  Per new row and
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
 // extrema_mark_kernel; survivors are queued (64 per batch, all lanes busy) for the exact
 // order-dependent test key_eval, which sets positional mask bits and row counts with atomics (the
 // masks are zeroed before the launch).
-constexpr int SX_PITCH = kStreamPitch, SX_ROWS = kStreamRows, SX_QCAP = 128;
+constexpr int SX_PITCH = kStreamPitch, SX_QCAP = 128;  // (rows per segment: Geom::stream_rows)
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
@@ -492,9 +492,9 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
   const OctGeom& og = g.o[o];
   const int task = ((int)blockIdx.x - og.stream_base) * 4 + wv;
   const int seg = task / og.strips, strip = task - seg * og.strips;
-  const int ys = seg * SX_ROWS;
+  const int ys = seg * g.stream_rows;
   if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
-  const int ye = min(ys + SX_ROWS, og.h);
+  const int ye = min(ys + g.stream_rows, og.h);
   const int cx = strip * SX_PITCH - NC + NC * lane;  // this lane's first column
   const bool col_in = cx >= 0 && cx < og.wa;         // (wa is a multiple of 4: a lane's columns are all in or all out)
   const int wa = og.wa, h = og.h;

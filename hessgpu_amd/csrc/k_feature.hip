@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   // workgroup, staged in LDS (the coefficient tables are not in use yet) and stored as contiguous 8-byte pieces --
   // 24-byte records stored one by one from a lane of every wavefront reached the pinned host mirror as as many
   // small PCIe writes and cost the kernel as much as the 512-byte descriptors did.
-  for (int f0 = blockIdx.x * 256; f0 < ftotal; f0 += gridDim.x * 256) {  // (uniform over the workgroup)
+  // (by the launch's LAST workgroups: the first ones hold the largest features and are the launch's critical path)
+  for (int f0 = (gridDim.x - 1 - blockIdx.x) * 256; f0 < ftotal; f0 += gridDim.x * 256) {  // (uniform over the workgroup)
     const int nrec = min(256, ftotal - f0);
     uint32_t* const kst = reinterpret_cast<uint32_t*>(&crow[0][0]);
     static_assert(sizeof(HostKeypoint) == 24 && 4 * DC_ROWS * 4 >= 256 * 24, "record staging fits the table");

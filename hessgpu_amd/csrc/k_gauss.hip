@@ -97,8 +97,14 @@ struct GaussArgs {
 
 __device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
 
+// LDS floats of one tile: (32 + 2R) staged rows of 64 + 2*R4 (+4 pad) columns
+template <int R>
+constexpr int gauss_tile_lds() { return (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4); }
+
+// One 64x32 tile of one level: the body of gauss_kernel, and of either half of gauss_pair_kernel.  `block` = the
+// workgroup's index among the launch's (or the half's) workgroups, `s` = gauss_tile_lds<R>() floats of LDS.
 template <int R, bool U8, bool HESS>
-__global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
+__device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict__ s, const int block) {
   constexpr int FW = 2 * R + 1;
   constexpr int R4 = (R + 3) & ~3;
   constexpr int OFF = R4 - R;
@@ -107,8 +113,7 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   constexpr int ROWS = TH + 2 * R;
   constexpr int NG = SW / 4;           // 16-byte groups per staged row
   constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
-
-  __shared__ __attribute__((aligned(16))) float s[ROWS * SWP];
+  static_assert(ROWS * SWP == gauss_tile_lds<R>(), "LDS size");
 
   const int tid = threadIdx.x;
   const int w = a.w, h = a.h;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   // neighbouring tiles -- which share halo rows/columns -- are served by the same 4 MiB L2.
   const int ntile = a.tiles_x * a.tiles_y * a.batch;
   const int per_xcd = (ntile + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int tile = (block & 7) * per_xcd + (block >> 3);
   if (tile >= ntile) return;
   const int tz = tile / (a.tiles_x * a.tiles_y);
   const int trem = tile - tz * (a.tiles_x * a.tiles_y);
@@ -346,6 +351,24 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   GSTAMP_VMWAIT();
   GSTAMP(6);  // stores draining
   GSTAMP_END;
+}
+
+template <int R, bool U8, bool HESS>
+__global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R>()];
+  gauss_tile<R, U8, HESS>(a, s, (int)blockIdx.x);
+}
+
+// Two level launches that do not depend on each other in one grid: the top level of octave o (taps RA, its source level
+// has a gradient plane) and level 1 of octave o+1 (taps RB) -- T(o, l) = 3o + l is the earliest step of level l of
+// octave o, so level 4 of one octave and level 1 of the next are due together.  The small half hides behind the large
+// one: six launches fewer in the dependent chain of a 1080p pyramid.  The first blocks_a workgroups do half a.
+template <int RA, int RB>
+__global__ __launch_bounds__(NT) void gauss_pair_kernel(GaussArgs a, GaussArgs b, int blocks_a) {
+  constexpr int LDS = gauss_tile_lds<RA>() > gauss_tile_lds<RB>() ? gauss_tile_lds<RA>() : gauss_tile_lds<RB>();
+  __shared__ __attribute__((aligned(16))) float s[LDS];
+  if ((int)blockIdx.x < blocks_a) gauss_tile<RA, false, true>(a, s, (int)blockIdx.x);  // (workgroup-uniform)
+  else gauss_tile<RB, false, true>(b, s, (int)blockIdx.x - blocks_a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -788,6 +811,55 @@ extern "C" int hess_debug_gauss_stamps(unsigned long long* out) {  // out[8]: su
 }
 namespace hess {
 #endif
+
+namespace {
+GaussArgs job_args(const GaussJob& j, int batch) {
+  GaussArgs a;
+  a.decim_dst = j.decim_dst; a.dw = j.decim_w; a.dh = j.decim_h;
+  a.src = j.src; a.src_u8 = nullptr; a.src_pitch = j.wa; a.src_img_stride = (long long)j.wa * j.h;
+  a.dst = j.dst; a.w = j.wa; a.h = j.h; a.taps = j.taps;
+  a.deth_src = j.deth_src; a.got_src = reinterpret_cast<float2*>(j.got_src); a.norm_src = j.norm_src;
+  a.tiles_x = (j.wa + TW - 1) / TW; a.tiles_y = (j.h + TH - 1) / TH; a.batch = batch;
+  a.rows_per_wg = 0; a.nwg = 0;
+  return a;
+}
+template <int RA, int RB>
+void launch_pair(hipStream_t st, const GaussArgs& a, const GaussArgs& b) {
+  const int na = ((a.tiles_x * a.tiles_y * a.batch + 7) / 8) * 8, nb = ((b.tiles_x * b.tiles_y * b.batch + 7) / 8) * 8;
+  hipLaunchKernelGGL((gauss_pair_kernel<RA, RB>), dim3(na + nb), dim3(NT), 0, st, a, b, na);
+}
+template <int RA>
+bool launch_pair_b(hipStream_t st, const GaussArgs& a, const GaussArgs& b, int rb) {
+  switch (rb) {
+    case 4: launch_pair<RA, 4>(st, a, b); return true;
+    case 5: launch_pair<RA, 5>(st, a, b); return true;
+    case 6: launch_pair<RA, 6>(st, a, b); return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+// Level launches a (the larger: top level of an octave) and b (level 1 of the next octave) in one grid.  Instantiated
+// for the tap counts around the reference's default schedule (a: 17-25 taps, b: 9-13); false = not this pair, launch
+// them one after the other.
+bool launch_gauss_pair(hipStream_t st, const GaussJob& ja, const GaussJob& jb, int batch) {
+#if HESS_GAUSS_TILES
+  if (!ja.deth_src || !jb.deth_src) return false;
+  const GaussArgs a = job_args(ja, batch), b = job_args(jb, batch);
+  const int rb = jb.taps.fw >> 1;
+  switch (ja.taps.fw >> 1) {
+    case 8: return launch_pair_b<8>(st, a, b, rb);
+    case 9: return launch_pair_b<9>(st, a, b, rb);
+    case 10: return launch_pair_b<10>(st, a, b, rb);
+    case 11: return launch_pair_b<11>(st, a, b, rb);
+    case 12: return launch_pair_b<12>(st, a, b, rb);
+    default: return false;
+  }
+#else
+  (void)st; (void)ja; (void)jb; (void)batch;
+  return false;
+#endif
+}
 
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
                     long long img_stride, int ds, float* dst, int w, int h, int batch) {
