@@ -472,7 +472,7 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         out.append({
             "bound": "hbm",
-            "kernel": "gauss_kernel (separable Gaussian + fused det-Hessian/gradient, one pyramid level of the batch per launch)",
+            "kernel": "gauss_kernel / gauss_pair_kernel (separable Gaussian + fused det-Hessian/gradient; one pyramid level of the batch per launch, the top level of an octave shares its launch with level 1 of the next)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profile_value("gauss_traffic.json", "hbm_bytes_per_launch"),
             "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
@@ -483,7 +483,7 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
         if mix:  # what this chip sustains for a level launch's traffic mix (4 B read, 16 B written per pixel)
             out[-1]["achievable_for_mix"] = {"peak": mix, "unit": "GB/s", "frac": round(achieved / mix, 4),
                                              "source": "tools/micro/hbm_mix.hip, one read to four writes (profiles/r03_hbm_mix.txt); "
-                                                       "the octave-0 launches alone run at 0.87-0.97 of it, the 24 latency-bound "
+                                                       "the octave-0 launches alone run at 0.87-0.97 of it, the latency-bound "
                                                        "launches of the smaller octaves pull the stage's average down"}
         gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
         if gi:

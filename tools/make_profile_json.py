@@ -26,7 +26,7 @@ def main():
     traffic["source"] = f"profiles/{tag}_* (tools/profile_round.sh {tag})"
     # vector instructions of all Gaussian launches per image: the SQ pass runs 3 steps (--steps 2 --warmup 1) of one batch
     batch = bench["config"]["images_per_gpu_per_step"]
-    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith("gauss_kernel"))
+    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel")))
     traffic["valu_insts_per_image"] = round(gv / (3 * batch), 1)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
