@@ -289,7 +289,7 @@ def main():
                 out["roofline"]["leg"] = f"{roof_steps} single-stream steps after the timed region (kernels do not overlap)"
             if len(ranked) > 1:
                 out["roofline_secondary"] = ranked[1]
-            out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"]}
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"] and k != "gauss_octave0"}
         if host is not None:
             out.update(host)
         if api is not None:
@@ -485,6 +485,17 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
                                              "source": "tools/micro/hbm_mix.hip, one read to four writes (profiles/r03_hbm_mix.txt); "
                                                        "the octave-0 launches alone run at 0.87-0.97 of it, the latency-bound "
                                                        "launches of the smaller octaves pull the stage's average down"}
+        g0 = prof.get("gauss_octave0")
+        if g0 and g0["launches"]:
+            # the launches that work on octave 0 (three quarters of the stage's bytes): large enough to be bound by
+            # memory bandwidth; the rest of the stage is the dependent chain of small launches of the other octaves
+            a0 = g0["bytes"] / (g0["ms"] * 1e-3) / 1e9
+            out[-1]["octave0_launches"] = {
+                "launches": g0["launches"], "avg_launch_us": round(g0["ms"] * 1e3 / g0["launches"], 2),
+                "algorithmic_bytes_per_launch": round(g0["bytes"] / g0["launches"], 1),
+                "share_of_stage_bytes": round(g0["bytes"] / g["bytes"], 3), "share_of_stage_time": round(g0["ms"] / g["ms"], 3),
+                "achieved": round(a0, 1), "unit": "GB/s", "frac": round(a0 / HBM_PEAK_GBS, 4),
+                "frac_of_mix": round(a0 / mix, 4) if mix else None}
         gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
         if gi:
             rate = gi * images * steps / (g["ms"] * 1e-3) / 1e9

@@ -25,9 +25,9 @@ DBG_GAUSS, DBG_DETH, DBG_GOT = 0, 1, 2
 (T_LOAD, T_ALLOC, T_PYRAMID, T_DETECT, T_LIST, T_ORIENT, T_MULTI_ORIENT, T_DOWNLOAD,
  T_DESCRIPTOR, T_VBO, T_REDUCTION, T_TOTAL, T_COUNT) = range(13)
 (K_GAUSS, K_DOWNSAMPLE, K_HESSIAN, K_EXTREMA, K_TOPK, K_ORIENT, K_DESCRIPTOR, K_INPUT,
- K_COUNT) = range(9)
+ K_GAUSS_OCT0, K_COUNT) = range(10)
 KERNEL_NAMES = ["gauss", "downsample", "hessian", "extrema", "topk", "orient", "descriptor",
-                "input"]
+                "input", "gauss_octave0"]  # gauss_octave0 repeats the octave-0 launches counted in gauss
 
 
 class HessParams(C.Structure):

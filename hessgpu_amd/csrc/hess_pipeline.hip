@@ -51,6 +51,7 @@ struct EventPair {
   hipEvent_t a, b;
   int kernel;
   double bytes;
+  int kernel2 = -1;  // a second accumulator for the same launch (HESS_K_GAUSS_OCT0), or -1
 };
 
 }  // namespace
@@ -490,9 +491,9 @@ struct ProfScope {
   hess_ctx* c;
   EventPair ep;
   bool on;
-  ProfScope(hess_ctx* ctx, int kernel, double bytes) : c(ctx), on(ctx->prof) {
+  ProfScope(hess_ctx* ctx, int kernel, double bytes, int kernel2 = -1) : c(ctx), on(ctx->prof) {
     if (!on) return;
-    ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes;
+    ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes; ep.kernel2 = kernel2;
     if (!ep.a || !ep.b) {  // event creation failed: no record for this launch
       if (ep.a) c->pool.push_back(ep.a);
       if (ep.b) c->pool.push_back(ep.b);
@@ -514,6 +515,7 @@ void drain_profile(hess_ctx* c) {
       c->k_ms[ep.kernel] += ms;
       c->k_n[ep.kernel] += 1;
       c->k_bytes[ep.kernel] += ep.bytes;
+      if (ep.kernel2 >= 0) { c->k_ms[ep.kernel2] += ms; c->k_n[ep.kernel2] += 1; c->k_bytes[ep.kernel2] += ep.bytes; }
     }
     c->pool.push_back(ep.a);
     c->pool.push_back(ep.b);
@@ -600,7 +602,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     // image b of level l lives at plane_ptr(.., o, l) + b*plane: a batch is contiguous per level
     if (o == 0) {
       if (c->has_taps0) {
-        ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (direct_u8 ? 5.0 : 8.0));
+        ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (direct_u8 ? 5.0 : 8.0), HESS_K_GAUSS_OCT0);
         if (direct_u8)
           launch_gauss(st, nullptr, (const uint8_t*)dev, pitch, (long long)image_stride, plane_ptr(gauss, 0, 0),
                        og.wa, og.h, batch, c->taps0);
@@ -617,13 +619,13 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     for (int l = 1; l <= s.level_max; l++) {
       if (l == 1 && deferred_o >= 0) {  // the previous octave's top level rides with this octave's level 1
         const GaussJob ja = level_job(deferred_o, s.level_max), jb = level_job(o, 1);
-        ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max) + level_bytes(o, 1));
+        ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max) + level_bytes(o, 1), deferred_o == 0 ? HESS_K_GAUSS_OCT0 : -1);
         if (!launch_gauss_pair(st, ja, jb, batch)) { launch_level(ja); launch_level(jb); }
         deferred_o = -1;
         continue;
       }
       if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
-      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l));
+      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l), o == 0 ? HESS_K_GAUSS_OCT0 : -1);
       launch_level(level_job(o, l));
     }
   }

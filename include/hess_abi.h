@@ -217,9 +217,11 @@ const float* hess_timing(hess_ctx* ctx);
 const char* hess_last_error(hess_ctx* ctx);
 
 /* Per-kernel device-time accounting (hipEvents on the context's stream) for bench.py's
- * roofline leg.  Off by default.  Kernel ids: HESS_K_*. */
+ * roofline leg.  Off by default.  Kernel ids: HESS_K_*.  HESS_K_GAUSS_OCT0 repeats the Gaussian launches that work on
+ * octave 0 (they are counted in HESS_K_GAUSS as well): the launches large enough to be bound by memory bandwidth
+ * rather than by the latency of the dependent chain. */
 enum { HESS_K_GAUSS = 0, HESS_K_DOWNSAMPLE, HESS_K_HESSIAN, HESS_K_EXTREMA, HESS_K_TOPK,
-       HESS_K_ORIENT, HESS_K_DESCRIPTOR, HESS_K_INPUT, HESS_K_COUNT };
+       HESS_K_ORIENT, HESS_K_DESCRIPTOR, HESS_K_INPUT, HESS_K_GAUSS_OCT0, HESS_K_COUNT };
 int hess_profile_enable(hess_ctx* ctx, int on);
 /* Accumulated since the last hess_profile_reset: total ms, launches, algorithmic bytes. */
 int hess_profile_get(hess_ctx* ctx, int kernel, double* ms, long long* launches, double* bytes);

@@ -36,6 +36,9 @@ def test_bench_json_line():
     dk = rf if rf["kernel"].startswith("descriptor") else d["roofline_secondary"]
     assert dk["with_host_mirror"]["kernel"] == "descriptor_kernel<true>" and dk["with_host_mirror"]["avg_launch_us"] > 0
     assert dk["valu"]["peak"] == 1228.8 and 0 < dk["valu"]["frac"] < 1
+    gk = rf if rf["kernel"].startswith("gauss") else d["roofline_secondary"]
+    o0 = gk["octave0_launches"]  # the Gaussian launches of octave 0, timed apart: the bandwidth-bound part of the stage
+    assert o0["launches"] > 0 and 0 < o0["frac"] < 1 and o0["frac"] > gk["frac"] and 0.5 < o0["share_of_stage_bytes"] < 1
     assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
     assert 0 < d["value_host_to_host"] and 0 < d["latency_ms_single_image"] < 100
     assert d["config"]["distinct_images_per_gpu"] == 3 and "configs[1]" in d["config"]["workload"]
