@@ -31,6 +31,19 @@ constexpr int kStreamPitch = 62 * kStreamCols;     // lanes 1..62 own columns, l
 constexpr int kStreamRows = HESS_STREAM_ROWS;
 constexpr int kHistBins = 32768;  // abs(half) keys of the top-K selection
 
+// Streaming ("non-temporal") stores for the planes one stage writes and a much later one reads (det-H: the extrema
+// scan after the whole pyramid; gradient/theta: orientation and descriptors): they should not displace the Gaussian
+// level the NEXT launch is about to read from the last-level cache.  Same-call A/B, batches of 8: Gaussian stage
+// 0.546 -> 0.514 ms per step, headline + 2.7 % (profiles/r03_experiments/streaming_stores.txt).
+typedef float hess_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream_f4(float* p, float x, float y, float z, float w) {
+#ifdef HESS_NO_STREAM_STORES  // A/B build: plain stores
+  *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w);
+#else
+  __builtin_nontemporal_store((hess_v4f){x, y, z, w}, reinterpret_cast<hess_v4f*>(p));
+#endif
+}
+
 struct OctGeom {
   int wa, h;            // 4-aligned width, height (PyramidCU.cpp:274-309)
   int plane;            // wa*h

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float*
       const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;       // :538
       hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;             // :553
     }
-    *reinterpret_cast<float4*>(deth + poff + row * wa + x) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    store_stream_f4(deth + poff + row * wa + x, hv[0], hv[1], hv[2], hv[3]);
   }
 }
 

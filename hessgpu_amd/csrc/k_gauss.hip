@@ -252,11 +252,11 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
           }
         }
         const long long o = img * (long long)w * h + idx;
-        *reinterpret_cast<float4*>(a.deth_src + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        store_stream_f4(a.deth_src + o, hv[0], hv[1], hv[2], hv[3]);
         if (want_got) {
-          float2* gp = a.got_src + o;
-          *reinterpret_cast<float4*>(gp) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
-          *reinterpret_cast<float4*>(gp + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
+          float* gp = reinterpret_cast<float*>(a.got_src + o);
+          store_stream_f4(gp, gv[0].x, gv[0].y, gv[1].x, gv[1].y);
+          store_stream_f4(gp + 4, gv[2].x, gv[2].y, gv[3].x, gv[3].y);
         }
       }
     }
