@@ -495,11 +495,7 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
   const int ys = seg * g.stream_rows;
   if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
   const int ye = min(ys + g.stream_rows, og.h);
-#ifdef HESS_AB_ALIGNED_WINDOWS  // EXPERIMENT (wrong results at strip borders): what the scan costs without straddled lines
-  const int cx = strip * 128 + NC * lane;
-#else
   const int cx = strip * SX_PITCH - NC + NC * lane;  // this lane's first column
-#endif
   const bool col_in = cx >= 0 && cx < og.wa;         // (wa is a multiple of 4: a lane's columns are all in or all out)
   const int wa = og.wa, h = og.h;
   const long long lstep = (long long)g.B * og.plane;
