@@ -68,8 +68,11 @@ def main():
     ap.add_argument("--no-api-leg", action="store_true", help="skip the libsiftgpu.so (RunSIFT + GetFeatureVector) legs")
     ap.add_argument("--no-configs4", action="store_true", help="skip the 4096x4096 leg (BASELINE.json configs[4])")
     ap.add_argument("--api-threads", type=int, default=8, help="SiftGPU instances (host threads) of the multi-instance leg")
-    ap.add_argument("--gather-dest", choices=("host", "hbm"), default="host",
-                    help="N > 1: where the gathered feature lists end on rank 0 (host = pinned host memory, like N = 1)")
+    ap.add_argument("--gather-dest", choices=("shm", "host", "hbm"), default="shm",
+                    help="N > 1: where rank 0 finds the feature lists of the global batch after the RCCL gather: shm = "
+                         "also in host memory, read in place from the node-shared pinned buffers every rank's own "
+                         "copier delivers into (each GPU over its own host link); host = rank 0 copies the gathered "
+                         "lists from its HBM to pinned memory through its own link; hbm = in rank 0's HBM only")
     ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "
                     "the headline workload uses the default (all 7 octaves of 1920x1080)")
     args = ap.parse_args()
@@ -135,8 +138,21 @@ def main():
     ctxs = [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
                                     octave_num=args.octaves)
             for _ in range(nctx)]
+    readers = None
+    if use_dist and args.gather_dest == "shm":
+        # every rank keeps its contexts' pinned result buffers in shared memory of the node; rank 0 maps them
+        tok = [f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}"] if rank == 0 else [None]
+        tdist.broadcast_object_list(tok, src=0, group=hdist.count_group())
+        names = [f"hessbench_{tok[0]}_r{rank}_c{j}" for j in range(nctx)]
+        for c, nm in zip(ctxs, names):
+            c.share_results(nm)
     for c in ctxs:
         c.reserve(W, H, B)
+    if use_dist and args.gather_dest == "shm":
+        tdist.barrier()   # the directories of every rank exist
+        if rank == 0:
+            readers = {r: [hdist.SharedResultsReader(f"hessbench_{tok[0]}_r{r}_c{j}") for j in range(nctx)]
+                       for r in range(1, world)}
     landing = hdist.HostLanding() if (use_dist and args.gather_dest == "host") else None
     gathered = {}
 
@@ -150,6 +166,10 @@ def main():
                 if landing is not None:   # the other ranks' lists into pinned host memory: the step ends where N = 1 ends
                     gk, gd = landing.land(gk, gd, own_rank=0)
                 gathered["counts"], gathered["keys"], gathered["desc"] = allc, gk, gd
+                if readers is not None:   # ... or read in place where every rank's copier has put them
+                    slot = ctxs.index(c)
+                    dim = c.desc_dim()
+                    gathered["host"] = {r: readers[r][slot].views(int(sum(allc[r])), dim) for r in readers}
         return counts
 
     def run_steps(n, submit):
@@ -192,8 +212,12 @@ def main():
     if use_dist and rank == 0 and gathered:
         for r in range(1, world):
             n0 = gathered["counts"][r][0]
-            gathered_first[r] = (gathered["keys"][r][:n0].cpu().numpy().copy(),
-                                 gathered["desc"][r][:n0].cpu().numpy().copy())
+            if "host" in gathered:   # the node-shared host buffers are what rank 0 would hand on: check those
+                hk, hd = gathered["host"][r]
+                gathered_first[r] = (hk[:n0].copy(), hd[:n0].copy())
+            else:
+                gathered_first[r] = (gathered["keys"][r][:n0].cpu().numpy().copy(),
+                                     gathered["desc"][r][:n0].cpu().numpy().copy())
 
     # Legs outside the timed region (rank 0 alone reports them; every rank runs the device ones to stay in step).
     # Roofline leg: per-kernel hipEvent durations are only meaningful when kernels of different streams do not
@@ -269,7 +293,8 @@ def main():
                 "distinct_images_per_gpu": nd,
                 "features_per_image_mean": round(float(np.mean(counts)), 1),
                 "sharding": (f"images over {world} rank(s), exact-size RCCL send/recv of the feature lists to rank 0"
-                             + (", landed in rank 0's pinned host memory" if landing is not None else " (HBM)")
+                             + (", landed in rank 0's pinned host memory" if landing is not None else
+                                " (HBM); every rank's lists also in node-shared pinned host memory, mapped by rank 0" if readers is not None or (use_dist and args.gather_dest == "shm") else " (HBM)")
                              if use_dist else "single GPU"),
                 "input": "u8 luminance resident in HBM; results delivered to host memory",
                 "result_delivery": "copier thread: DMA copy of the exact byte count, no dependency on a kernel "

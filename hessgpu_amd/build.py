@@ -21,7 +21,7 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
 
 # ROCr itself, beside the HIP runtime: the copier thread hands its device->host copies straight to an SDMA engine
 # (hsa_amd_memory_async_copy_on_engine, csrc/hess_pipeline.hip)
-LINK_LIBS = ["-lhsa-runtime64"]
+LINK_LIBS = ["-lhsa-runtime64", "-lrt"]
 KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_pipeline.hip", "hess_match.hip"]
 # Per-file flags.  k_feature.hip: the SLP vectoriser turns pairs of FP32 operations into packed
 # instructions (v_pk_add/mul/fma_f32), which on gfx950 issue at half rate (tools/micro/README.md) and need

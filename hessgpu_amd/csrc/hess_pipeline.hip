@@ -17,6 +17,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/hess_abi.h"
 #include "hess_dev.h"
@@ -45,6 +51,7 @@ struct Schedule {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  std::string shm;  // non-empty: p is a registered mapping of this POSIX shared memory object (hess_share_results)
 };
 
 struct EventPair {
@@ -152,6 +159,10 @@ struct hess_ctx {
   std::vector<int> counts;
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
+  // hess_share_results: the two result buffers live in shared memory objects "/<share>.k<n>" / "/<share>.d<n>" that
+  // another process of the node can map; a 4 KB directory object "/<share>.h" says which ones are current
+  std::string share;
+  struct ShareDir { uint32_t magic, gen_keys, gen_desc, pad; uint64_t keys_bytes, desc_bytes; }* share_dir = nullptr;
   DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
   size_t last_input_bytes = 0;     // bytes of the last batch handed over by hess_submit_host (still in `stage`)
   hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
@@ -213,8 +224,11 @@ void set_err(hess_ctx* c, const char* fmt, ...) {
     }                                                                                     \
   } while (0)
 
+int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which);
+
 int ensure(hess_ctx* c, DevBuf& b, size_t bytes, bool pinned_host = false) {
   if (bytes <= b.bytes) return 0;
+  if (pinned_host && c->share_dir && (&b == &c->h_keys || &b == &c->h_desc)) return ensure_shared(c, b, bytes, &b == &c->h_keys ? 'k' : 'd');
   // the new buffer first: when the allocation fails the old one is still there (a context survives a refused
   // hess_reserve)
   const size_t want = bytes + bytes / 8;  // slack so slightly larger inputs do not reallocate
@@ -228,9 +242,58 @@ int ensure(hess_ctx* c, DevBuf& b, size_t bytes, bool pinned_host = false) {
 }
 
 void release(DevBuf& b, bool pinned_host = false) {
-  if (b.p) { if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+  if (b.p && !b.shm.empty()) {
+    (void)hipHostUnregister(b.p);
+    (void)munmap(b.p, b.bytes);
+    (void)shm_unlink(b.shm.c_str());
+    b.shm.clear();
+  } else if (b.p) {
+    if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
+  }
   b.p = nullptr;
   b.bytes = 0;
+}
+
+// A pinned result buffer of a context whose results are shared with other processes of the node (hess_share_results):
+// a POSIX shared memory object, mapped and registered with the runtime, so that the copier's DMA copy (or the
+// descriptor kernel's own stores) lands in memory the consumer process has mapped as well -- every GPU of a node
+// delivers over its own host link and nothing is funnelled through one rank's.  `which` is 'k' or 'd'.
+int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which) {
+  if (bytes <= b.bytes) return 0;
+  const long page = sysconf(_SC_PAGESIZE);
+  size_t want = bytes + bytes / 8;
+  want = (want + (size_t)page - 1) / (size_t)page * (size_t)page;
+  uint32_t& gen = which == 'k' ? c->share_dir->gen_keys : c->share_dir->gen_desc;
+  char name[256];
+  snprintf(name, sizeof(name), "/%s.%c%u", c->share.c_str(), which, gen + 1);
+  (void)shm_unlink(name);  // a stale object of a dead job with the same name
+  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", name, strerror(errno)); return HESS_ERR_NOMEM; }
+  if (ftruncate(fd, (off_t)want) != 0) {
+    set_err(c, "ftruncate(%s, %zu) failed: %s", name, want, strerror(errno));
+    close(fd); shm_unlink(name);
+    return HESS_ERR_NOMEM;
+  }
+  void* np = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
+  close(fd);
+  if (np == MAP_FAILED) { set_err(c, "mmap(%s) failed: %s", name, strerror(errno)); shm_unlink(name); return HESS_ERR_NOMEM; }
+  void* dp = nullptr;
+  hipError_t e = hipHostRegister(np, want, hipHostRegisterPortable | hipHostRegisterMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, np, 0);
+  if (e != hipSuccess || dp != np) {  // (the kernels and the copier address the buffer by its host pointer)
+    if (e == hipSuccess) (void)hipHostUnregister(np);
+    else (void)hipGetLastError();
+    set_err(c, "cannot register the shared result buffer %s with the runtime: %s", name,
+            e != hipSuccess ? hipGetErrorString(e) : "device alias differs from the host address");
+    munmap(np, want); shm_unlink(name);
+    return e == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;
+  }
+  release(b, true);
+  b.p = np; b.bytes = want; b.shm = name;
+  gen++;
+  (which == 'k' ? c->share_dir->keys_bytes : c->share_dir->desc_bytes) = want;
+  __sync_synchronize();
+  return 0;
 }
 
 // ---- parameters: GlobalUtil.cpp:51-144 defaults, SiftParam::ParseSiftParam SiftGPU.cpp:491-563 ----
@@ -921,7 +984,9 @@ bool copier_hsa_setup(hess_ctx* c) {
   cp.gpu_agent = pi.agentOwner;
   memset(&pi, 0, sizeof(pi));
   pi.size = sizeof(pi);
-  if (hsa_amd_pointer_info(c->h_keys.p, &pi, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pi.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+  // (the host side from the count block: always the runtime's own pinned allocation, also when the result buffers
+  // are registered shared memory, whose owner ROCr reports differently)
+  if (hsa_amd_pointer_info(c->h_small.p, &pi, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pi.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
   cp.cpu_agent = pi.agentOwner;
   if (hsa_signal_create(0, 0, nullptr, &cp.sig) != HSA_STATUS_SUCCESS) return false;
   uint32_t pref = 0;
@@ -1243,6 +1308,11 @@ void hess_destroy(hess_ctx* c) {
   release(c->h_keys, true);
   release(c->h_desc, true);
   release(c->h_small, true);
+  if (c->share_dir) {
+    (void)munmap(c->share_dir, 4096);
+    (void)shm_unlink(("/" + c->share + ".h").c_str());
+    c->share_dir = nullptr;
+  }
   release(c->h_stage, true);
   if (c->have_ev) {
     for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1483,6 +1553,40 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
 }
 
 int hess_debug_regrown(hess_ctx* c) { return c ? c->regrown : HESS_ERR_ARG; }
+
+int hess_share_results(hess_ctx* c, const char* name) {
+  if (!c || !name || !name[0] || strlen(name) > 200 || strchr(name, '/')) return HESS_ERR_ARG;
+  if (c->pend) { set_err(c, "a batch is in flight"); return HESS_ERR_ARG; }
+  if (c->share_dir) { set_err(c, "the results of this context are shared already (as %s)", c->share.c_str()); return HESS_ERR_ARG; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const std::string dir = std::string("/") + name + ".h";
+  (void)shm_unlink(dir.c_str());
+  const int fd = shm_open(dir.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", dir.c_str(), strerror(errno)); return HESS_ERR_NOMEM; }
+  void* m = ftruncate(fd, 4096) == 0 ? mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+  close(fd);
+  if (m == MAP_FAILED) { set_err(c, "cannot map %s: %s", dir.c_str(), strerror(errno)); shm_unlink(dir.c_str()); return HESS_ERR_NOMEM; }
+  memset(m, 0, 4096);
+  c->share = name;
+  c->share_dir = static_cast<hess_ctx::ShareDir*>(m);
+  c->share_dir->magic = 0x48455353u;  // "HESS"
+  // results of an earlier run stay readable through hess_fetch only until the next run: the buffers move now
+  if (c->st) HIP_TRY(c, hipStreamSynchronize(c->st));
+  release(c->h_keys, true);
+  release(c->h_desc, true);
+  c->planned = false;
+  c->batch = 0;
+  return 0;
+}
+
+int hess_shared_results_info(hess_ctx* c, unsigned* gen_keys, unsigned* gen_desc, size_t* keys_bytes, size_t* desc_bytes) {
+  if (!c || !c->share_dir) return HESS_ERR_ARG;
+  if (gen_keys) *gen_keys = c->share_dir->gen_keys;
+  if (gen_desc) *gen_desc = c->share_dir->gen_desc;
+  if (keys_bytes) *keys_bytes = (size_t)c->share_dir->keys_bytes;
+  if (desc_bytes) *desc_bytes = (size_t)c->share_dir->desc_bytes;
+  return 0;
+}
 
 int hess_debug_list(hess_ctx* c, int img, hess_rawkey* out, int cap) {
   if (!c || !c->d_list || img < 0 || img >= c->batch) return HESS_ERR_ARG;

@@ -38,6 +38,12 @@ def enable_host_count_exchange(group=None):
     _count_group[group] = dist.new_group(ranks=ranks, backend="gloo")
 
 
+def count_group(group=None):
+    """The gloo side group of `group` (None when enable_host_count_exchange was not called): host-side control
+    messages of the job (object broadcasts, count exchange) travel there."""
+    return _count_group.get(group)
+
+
 def _exchange_counts(counts, dev, world, group):
     """all_gather of the per-image counts -> list[world][n_local] of ints."""
     local = torch.tensor(counts, dtype=torch.int32)
@@ -206,6 +212,75 @@ class HostLanding:
         if on_gpu:
             self._stream.synchronize()
         return self.keys, self.desc
+
+
+class SharedResultsReader:
+    """Reader side of hess_share_results (include/hess_abi.h): maps the result buffers another process of the node
+    keeps in POSIX shared memory and hands out zero-copy views of a batch's feature lists.
+
+    On one node every rank's results reach host memory over its own GPU's host link (the context's copier thread);
+    the rank that collects the global batch reads them in place instead of pulling them through its own link a second
+    time (HostLanding: 8 x 17.7 MB per step through one ~50 GB/s link is 2.8 ms against a 1 ms step at eight ranks).
+    The producer's hess_wait / run must have returned before the views are read -- the count exchange that tells the
+    reader how many records there are is that ordering -- and the views are valid until the producer submits the
+    context's next batch."""
+
+    _HDR = np.dtype([("magic", "<u4"), ("gen_keys", "<u4"), ("gen_desc", "<u4"), ("pad", "<u4"),
+                     ("keys_bytes", "<u8"), ("desc_bytes", "<u8")])
+
+    def __init__(self, name, shm_dir="/dev/shm"):
+        import mmap
+        import os
+        self._mmap, self._os = mmap, os
+        self._name, self._dir = name, shm_dir
+        fd = os.open(os.path.join(shm_dir, name + ".h"), os.O_RDONLY)
+        try:
+            self._hdr_map = mmap.mmap(fd, 4096, prot=mmap.PROT_READ)
+        finally:
+            os.close(fd)
+        self._hdr = np.frombuffer(self._hdr_map, dtype=self._HDR, count=1)
+        if int(self._hdr["magic"][0]) != 0x48455353:
+            raise RuntimeError(f"{name}.h is not a hess result directory")
+        self._maps = {"k": (0, None), "d": (0, None)}   # which -> (generation, mmap)
+
+    def _buffer(self, which, gen):
+        have, m = self._maps[which]
+        if have != gen:
+            if m is not None:
+                m.close()
+            fd = self._os.open(self._os.path.join(self._dir, f"{self._name}.{which}{gen}"), self._os.O_RDONLY)
+            try:
+                m = self._mmap.mmap(fd, 0, prot=self._mmap.PROT_READ)
+            finally:
+                self._os.close(fd)
+            self._maps[which] = (gen, m)
+        return m
+
+    def views(self, total, dim):
+        """-> (keys uint8 [total, 24], desc float32 [total, dim] or None): read-only numpy views of the first `total`
+        records of the producer's last batch."""
+        if total == 0:
+            return np.zeros((0, KEY_BYTES), np.uint8), (np.zeros((0, dim), np.float32) if dim else None)
+        gk, gd = int(self._hdr["gen_keys"][0]), int(self._hdr["gen_desc"][0])
+        keys = np.frombuffer(self._buffer("k", gk), dtype=np.uint8, count=total * KEY_BYTES).reshape(total, KEY_BYTES)
+        desc = None
+        if dim:
+            desc = np.frombuffer(self._buffer("d", gd), dtype=np.float32, count=total * dim).reshape(total, dim)
+        return keys, desc
+
+    def close(self):
+        self._hdr = None
+        for which, (_, m) in self._maps.items():
+            if m is not None:
+                try:
+                    m.close()
+                except BufferError:   # a view handed out earlier is still alive: the mapping goes with it
+                    pass
+        self._maps = {"k": (0, None), "d": (0, None)}
+        try:
+            self._hdr_map.close()
+        except BufferError:
+            pass
 
 
 class _NullContext:

@@ -195,6 +195,18 @@ class Session:
         """Times the context grew its feature storage after an overflow and ran the batch again (product only)."""
         return self._check(self._f["debug_regrown"](self._h))
 
+    # -- node-shared result buffers (product only; hess_abi.h, hess_share_results) --------
+    def share_results(self, name):
+        """Keep this context's pinned result buffers in POSIX shared memory objects "/<name>.h|.k<n>|.d<n>" so that
+        another process of the node reads them in place (dist.SharedResultsReader).  Before the first batch."""
+        self._check(self._f["share_results"](self._h, name.encode()))
+
+    def shared_results_info(self):
+        """-> (gen_keys, gen_desc, keys_bytes, desc_bytes) of the shared result buffers."""
+        gk, gd, kb, db = C.c_uint(), C.c_uint(), C.c_size_t(), C.c_size_t()
+        self._check(self._f["shared_results_info"](self._h, C.byref(gk), C.byref(gd), C.byref(kb), C.byref(db)))
+        return gk.value, gd.value, kb.value, db.value
+
     # -- profiling (product only) --------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._f["profile_enable"](self._h, int(on)))

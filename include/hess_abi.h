@@ -209,6 +209,19 @@ int hess_debug_key_levels(hess_ctx* ctx, const int* levels, int num);
  * again (the reference grows its lists per image, PyramidCU.cpp:393-397).  The environment variable
  * HESS_INITIAL_CAP=<n> makes a new context start with room for n detections per image so that tests can force it. */
 int hess_debug_regrown(hess_ctx* ctx);
+
+/* Multi-process jobs on one node (one process per GPU): keep this context's pinned host result buffers in
+ * POSIX shared memory so that another process of the node -- the rank that collects the global batch -- reads them in
+ * place.  Every GPU then delivers over its own host link; nothing is funnelled through the collecting rank's.
+ *   "/<name>.h"      4096-byte directory: { u32 magic 'HESS', u32 gen_keys, u32 gen_desc, u32 pad, u64 keys_bytes, u64 desc_bytes }
+ *   "/<name>.k<gen>" keypoint records of the last batch, images back to back (hess_keypoint[total])
+ *   "/<name>.d<gen>" descriptors of the last batch (float[total][dim])
+ * A generation number grows when a buffer is reallocated (a reader re-maps when it changes; the old object is
+ * unlinked).  The per-image counts travel by the job's own control channel (hess_count); the data of a batch is
+ * complete when hess_wait / hess_run_* has returned and stays until the context's next batch is submitted.
+ * Call after hess_create, before the first batch; the objects are unlinked by hess_destroy.  name: no '/'. */
+int hess_share_results(hess_ctx* ctx, const char* name);
+int hess_shared_results_info(hess_ctx* ctx, unsigned* gen_keys, unsigned* gen_desc, size_t* keys_bytes, size_t* desc_bytes);
 /* Raw detections of image `img` in list order; returns the count (<= cap written). */
 int hess_debug_list(hess_ctx* ctx, int img, hess_rawkey* out, int cap);
 
