@@ -135,25 +135,40 @@ def main():
     # Contexts used round-robin: while one batch's results travel to the host (and, for N > 1, are gathered over
     # RCCL), the next batches' kernels already run on the other contexts' streams.
     nctx = max(1, args.contexts)
-    ctxs = [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
-                                    octave_num=args.octaves)
-            for _ in range(nctx)]
+    def make_contexts():
+        return [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
+                                        octave_num=args.octaves) for _ in range(nctx)]
+
+    ctxs = make_contexts()
     readers = None
-    if use_dist and args.gather_dest == "shm":
+    gather_dest = args.gather_dest if use_dist else None
+    if gather_dest == "shm":
         # every rank keeps its contexts' pinned result buffers in shared memory of the node; rank 0 maps them
         tok = [f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}"] if rank == 0 else [None]
+        shm_prefix = os.environ.get("HESS_BENCH_SHM_PREFIX", "hessbench")   # (a prefix with a '/' rehearses the fallback)
         tdist.broadcast_object_list(tok, src=0, group=hdist.count_group())
-        names = [f"hessbench_{tok[0]}_r{rank}_c{j}" for j in range(nctx)]
-        for c, nm in zip(ctxs, names):
-            c.share_results(nm)
+        ok = 1
+        try:
+            for j, c in enumerate(ctxs):
+                c.share_results(f"{shm_prefix}_{tok[0]}_r{rank}_c{j}")
+                c.reserve(W, H, B)
+        except Exception as e:   # e.g. /dev/shm too small for this job
+            print(f"bench.py: rank {rank}: node-shared result buffers unavailable ({e})", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)   # every rank takes the same decision
+        if int(flag.item()) == 0:
+            gather_dest = "host"   # the landing through rank 0's host link instead
+            for c in ctxs:
+                c.close()
+            ctxs = make_contexts()
     for c in ctxs:
         c.reserve(W, H, B)
-    if use_dist and args.gather_dest == "shm":
-        tdist.barrier()   # the directories of every rank exist
-        if rank == 0:
-            readers = {r: [hdist.SharedResultsReader(f"hessbench_{tok[0]}_r{r}_c{j}") for j in range(nctx)]
+    if gather_dest == "shm":
+        if rank == 0:   # (the all_reduce above is the barrier: every rank's directories exist)
+            readers = {r: [hdist.SharedResultsReader(f"{shm_prefix}_{tok[0]}_r{r}_c{j}") for j in range(nctx)]
                        for r in range(1, world)}
-    landing = hdist.HostLanding() if (use_dist and args.gather_dest == "host") else None
+    landing = hdist.HostLanding() if gather_dest == "host" else None
     gathered = {}
 
     def finish(c):
@@ -294,9 +309,10 @@ def main():
                 "features_per_image_mean": round(float(np.mean(counts)), 1),
                 "sharding": (f"images over {world} rank(s), exact-size RCCL send/recv of the feature lists to rank 0"
                              + (", landed in rank 0's pinned host memory" if landing is not None else
-                                " (HBM); every rank's lists also in node-shared pinned host memory, mapped by rank 0" if readers is not None or (use_dist and args.gather_dest == "shm") else " (HBM)")
+                                " (HBM); every rank's lists also in node-shared pinned host memory, mapped by rank 0" if gather_dest == "shm" else " (HBM)")
                              if use_dist else "single GPU"),
                 "input": "u8 luminance resident in HBM; results delivered to host memory",
+                **({"gather_dest": gather_dest} if use_dist else {}),
                 "result_delivery": "copier thread: DMA copy of the exact byte count, no dependency on a kernel "
                                    "(batches of 1-2 images: stores of the descriptor kernel into pinned memory)",
             },

@@ -269,8 +269,11 @@ int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which) {
   (void)shm_unlink(name);  // a stale object of a dead job with the same name
   const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
   if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", name, strerror(errno)); return HESS_ERR_NOMEM; }
-  if (ftruncate(fd, (off_t)want) != 0) {
-    set_err(c, "ftruncate(%s, %zu) failed: %s", name, want, strerror(errno));
+  // (posix_fallocate, not ftruncate: a full /dev/shm must fail here, not as a bus error at the first store)
+  int fe = posix_fallocate(fd, 0, (off_t)want);
+  if (fe == EOPNOTSUPP || fe == EINVAL) fe = ftruncate(fd, (off_t)want) == 0 ? 0 : errno;
+  if (fe != 0) {
+    set_err(c, "cannot size the shared result buffer %s to %zu bytes: %s", name, want, strerror(fe));
     close(fd); shm_unlink(name);
     return HESS_ERR_NOMEM;
   }
@@ -1555,7 +1558,11 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
 int hess_debug_regrown(hess_ctx* c) { return c ? c->regrown : HESS_ERR_ARG; }
 
 int hess_share_results(hess_ctx* c, const char* name) {
-  if (!c || !name || !name[0] || strlen(name) > 200 || strchr(name, '/')) return HESS_ERR_ARG;
+  if (!c) return HESS_ERR_ARG;
+  if (!name || !name[0] || strlen(name) > 200 || strchr(name, '/')) {
+    set_err(c, "hess_share_results: the name must be 1..200 characters without '/'");
+    return HESS_ERR_ARG;
+  }
   if (c->pend) { set_err(c, "a batch is in flight"); return HESS_ERR_ARG; }
   if (c->share_dir) { set_err(c, "the results of this context are shared already (as %s)", c->share.c_str()); return HESS_ERR_ARG; }
   HIP_TRY(c, hipSetDevice(c->device));
