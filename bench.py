@@ -79,6 +79,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HESS_BENCH_SAME_GPU") == "1":   # rehearsal of the N > 1 control flow on a one-GPU box (with HESS_BENCH_BACKEND=gloo)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # one process per GPU: keep this rank's host threads on the CPUs next to its GPU -- before any GPU call, so that
     # the runtime's threads and pinned allocations inherit the binding (one rank alone on a node keeps all its CPUs)
@@ -116,7 +118,11 @@ def main():
         os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("HESS_BENCH_BACKEND", "nccl")   # "gloo": rehearsal only (ranks sharing one GPU cannot form an RCCL group)
+        if backend == "nccl":
+            tdist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            tdist.init_process_group(backend=backend)
         # per-image counts travel over a gloo side group (host, loopback: one node), the payload over RCCL
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         try:

@@ -51,3 +51,24 @@ def test_bench_json_line():
     assert c4["Mpix_per_s_one_context"] > 0 and c4["Mpix_per_s_three_contexts"] > 0
     r4 = c4["roofline_descriptor"]
     assert r4["bound"] == "hbm" and r4["peak"] == 8000.0 and 0 < r4["frac"] < 1 and r4["features_per_launch"] == c4["features"]
+
+
+def test_two_rank_control_flow_on_one_gpu():
+    """The N > 1 path of bench.py rehearsed with two ranks that share the one GPU (gloo instead of RCCL, which cannot
+    form a group of ranks on the same device): count exchange, gather, rank 0 reading rank 1's lists in place from
+    the node-shared result buffers, and image 0 of BOTH ranks compared with the oracle out of those buffers."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HESS_BENCH_BACKEND="gloo", HESS_BENCH_SAME_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "2", "--no-profile"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather_dest"] == "shm"
+    assert d["parity_checked"] is True and d["parity_checked_ranks"] == 2
+    assert abs(d["value"] - 2 * 2 * 4 * 1920 * 1080 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.01
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("hessbench_")]
