@@ -292,7 +292,15 @@ int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which) {
     return e == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;
   }
   release(b, true);
-  b.p = np; b.bytes = want; b.shm = name;
+  try {
+    b.shm = name;
+  } catch (...) {  // (nothing thrown crosses the C ABI)
+    (void)hipHostUnregister(np);
+    munmap(np, want); shm_unlink(name);
+    set_err(c, "out of memory");
+    return HESS_ERR_NOMEM;
+  }
+  b.p = np; b.bytes = want;
   gen++;
   (which == 'k' ? c->share_dir->keys_bytes : c->share_dir->desc_bytes) = want;
   __sync_synchronize();
@@ -1313,7 +1321,9 @@ void hess_destroy(hess_ctx* c) {
   release(c->h_small, true);
   if (c->share_dir) {
     (void)munmap(c->share_dir, 4096);
-    (void)shm_unlink(("/" + c->share + ".h").c_str());
+    char dir[256];
+    snprintf(dir, sizeof(dir), "/%s.h", c->share.c_str());
+    (void)shm_unlink(dir);
     c->share_dir = nullptr;
   }
   release(c->h_stage, true);
@@ -1566,15 +1576,18 @@ int hess_share_results(hess_ctx* c, const char* name) {
   if (c->pend) { set_err(c, "a batch is in flight"); return HESS_ERR_ARG; }
   if (c->share_dir) { set_err(c, "the results of this context are shared already (as %s)", c->share.c_str()); return HESS_ERR_ARG; }
   HIP_TRY(c, hipSetDevice(c->device));
-  const std::string dir = std::string("/") + name + ".h";
-  (void)shm_unlink(dir.c_str());
-  const int fd = shm_open(dir.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-  if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", dir.c_str(), strerror(errno)); return HESS_ERR_NOMEM; }
+  char dir[256];
+  snprintf(dir, sizeof(dir), "/%s.h", name);
+  try {
+    c->share = name;  // (nothing thrown crosses the C ABI)
+  } catch (...) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
+  (void)shm_unlink(dir);
+  const int fd = shm_open(dir, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", dir, strerror(errno)); c->share.clear(); return HESS_ERR_NOMEM; }
   void* m = ftruncate(fd, 4096) == 0 ? mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
   close(fd);
-  if (m == MAP_FAILED) { set_err(c, "cannot map %s: %s", dir.c_str(), strerror(errno)); shm_unlink(dir.c_str()); return HESS_ERR_NOMEM; }
+  if (m == MAP_FAILED) { set_err(c, "cannot map %s: %s", dir, strerror(errno)); shm_unlink(dir); c->share.clear(); return HESS_ERR_NOMEM; }
   memset(m, 0, 4096);
-  c->share = name;
   c->share_dir = static_cast<hess_ctx::ShareDir*>(m);
   c->share_dir->magic = 0x48455353u;  // "HESS"
   // results of an earlier run stay readable through hess_fetch only until the next run: the buffers move now
