@@ -85,7 +85,7 @@ def main():
     # one process per GPU: keep this rank's host threads on the CPUs next to its GPU -- before any GPU call, so that
     # the runtime's threads and pinned allocations inherit the binding (one rank alone on a node keeps all its CPUs)
     bound = None
-    if world > 1 or os.environ.get("HESS_BENCH_FORCE_DIST") == "1":
+    if world > 1 or os.environ.get("HESS_BENCH_FORCE_DIST") == "1" or os.environ.get("HESS_BENCH_BIND") == "1":
         from hessgpu_amd import numa
         bound = numa.bind_to_gpu(local_rank)
 

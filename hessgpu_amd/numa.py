@@ -35,11 +35,16 @@ def gpu_pci_addresses(root="/"):
     out = []
     for n in sorted((d for d in os.listdir(base) if d.isdigit()), key=int):
         props = {}
-        with open(os.path.join(base, n, "properties")) as f:
-            for line in f:
-                kv = line.split()
-                if len(kv) == 2:
-                    props[kv[0]] = int(kv[1])
+        try:
+            with open(os.path.join(base, n, "properties")) as f:
+                for line in f:
+                    kv = line.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = int(kv[1])
+        except OSError:
+            # a GPU of the host that this process may not use (a container that was given some of the host's GPUs:
+            # the read is refused): it is not a HIP device here either, so it does not take an ordinal
+            continue
         if props.get("simd_count", 0) <= 0:
             continue
         loc, dom = props.get("location_id", 0), props.get("domain", 0)

@@ -39,3 +39,18 @@ def test_bind_is_a_no_op_without_topology(tmp_path):
     before = os.sched_getaffinity(0)
     assert numa.bind_to_gpu(0, str(tmp_path / "nothing"), env={}) is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_gpus_of_the_host_that_the_process_may_not_read_take_no_ordinal(tmp_path):
+    """A container that was given one of the host's GPUs sees all KFD nodes, but reading the others' properties is
+    refused (seen on the GPU pool): HIP device 0 is the one readable GPU node."""
+    import shutil
+    root = _tree(tmp_path, [(0x05, 0, 0, "0-7"), (0x26, 0, 0, "8-15"), (0xc5, 0, 0, "64-71")])
+    base = tmp_path / "sys/class/kfd/kfd/topology/nodes"
+    for n in ("1", "3"):   # unreadable: a directory in place of the file raises an OSError on open, like EPERM does on read
+        os.unlink(base / n / "properties")
+        (base / n / "properties").mkdir()
+    assert numa.gpu_pci_addresses(root) == ["0000:26:00.0"]
+    assert numa.local_cpus(0, root, env={}) == list(range(8, 16))
+    assert numa.local_cpus(1, root, env={}) is None
+    shutil.rmtree(base / "1" / "properties")
