@@ -1338,10 +1338,42 @@ void hess_destroy(hess_ctx* c) {
   delete c;
 }
 
+// The runtime objects a batch of this size will need are created by hess_reserve, not by the first batch (half a
+// millisecond of a context's first run otherwise): the copier thread and its binding to ROCr incl. the SDMA engine's
+// queue (a 64-byte copy into the keypoint buffer, only while the context holds no results), and the hardware queue
+// behind the context's stream (a 64-byte fill of the cleared area, which every batch clears first anyway).
+static int prime(hess_ctx* c, int batch) {
+  if (c->pend && c->pend->active) return 0;
+  choose_delivery(c, batch);
+  if (c->delivery == kDeliverDma && c->batch == 0 && c->keys.p && c->h_keys.p && c->h_keys.bytes >= 64 && !c->cp.has_job) {
+    Copier& cp = c->cp;
+    if (copier_hsa_setup(c)) {
+      auto tiny = [&](void* dst, const void* src) {
+        hsa_signal_store_relaxed(cp.sig, 1);
+        hsa_status_t st = cp.engine
+            ? hsa_amd_memory_async_copy_on_engine(dst, cp.cpu_agent, src, cp.gpu_agent, 64, 0, nullptr, cp.sig,
+                                                  (hsa_amd_sdma_engine_id_t)cp.engine, false)
+            : hsa_amd_memory_async_copy(dst, cp.cpu_agent, src, cp.gpu_agent, 64, 0, nullptr, cp.sig);
+        if (st == HSA_STATUS_SUCCESS)
+          while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+      };
+      tiny(c->h_keys.p, c->keys.p);
+      if (c->dim && c->desc.p && c->h_desc.p && c->h_desc.bytes >= 64) tiny(c->h_desc.p, c->desc.p);
+    }
+  }
+  if (c->zeroed.p && c->zeroed.bytes >= 64) {
+    HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, 64, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+  }
+  return 0;
+}
+
 int hess_reserve(hess_ctx* c, int width, int height, int batch) {
   if (!c || width <= 0 || height <= 0 || batch <= 0) return HESS_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
-  return plan(c, width, height, batch);
+  const int rc = plan(c, width, height, batch);
+  if (rc) return rc;
+  return prime(c, batch);
 }
 
 static int check_run_args(hess_ctx* c, const void* pixels, int width, int height, int pitch, int batch, int format,
