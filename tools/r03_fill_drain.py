@@ -19,6 +19,8 @@ W, H, B, K = 1920, 1080, 8, int(sys.argv[1]) if len(sys.argv) > 1 else 20
 WARM = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [5]
 DEPTHS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 3, 4, 6]
 PRE_MS = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+PACE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
+last_sub = [None]
 imgs = np.stack([fixtures.synthetic_blobs(W, H, i) for i in range(B)])
 d = torch.from_numpy(imgs).cuda()
 for nctx in DEPTHS:
@@ -29,12 +31,17 @@ for nctx in DEPTHS:
     def run(n, stamps=None, t0=0.0):
         infl = []
         for i in range(n):
-            c = ctxs[i % nctx]
+            c = ctxs[i % nctx] if len(infl) < nctx else None
             if len(infl) == nctx:
-                infl.pop(0).wait()
+                c = infl.pop(0)
+                c.wait()
                 if stamps is not None:
                     stamps.append(time.perf_counter() - t0)
+            if PACE > 0 and last_sub[0] is not None:   # never two submissions closer than PACE ms
+                while (time.perf_counter() - last_sub[0]) * 1e3 < PACE:
+                    pass
             c.submit_device(d.data_ptr(), B, H, W)
+            last_sub[0] = time.perf_counter()
             if stamps is not None:
                 subs.append(time.perf_counter() - t0)
             infl.append(c)
@@ -62,7 +69,7 @@ for nctx in DEPTHS:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gaps = np.diff([0.0] + stamps) * 1e3
-        print(f"contexts {nctx}, {warm} warm-up steps after 0.5 s idle (+ {PRE_MS:.0f} ms of streaming): {K} steps in {dt*1e3:.2f} ms = {dt*1e3/K:.3f} ms/step = {B*K*W*H/dt/1e6:.0f} Mpix/s")
+        print(f"pace {PACE} ms, contexts {nctx}, {warm} warm-up steps after 0.5 s idle (+ {PRE_MS:.0f} ms of streaming): {K} steps in {dt*1e3:.2f} ms = {dt*1e3/K:.3f} ms/step = {B*K*W*H/dt/1e6:.0f} Mpix/s")
         print("   submit times (ms):", " ".join(f"{s_*1e3:.2f}" for s_ in subs[:8]), "...")
         print("   completion gaps (ms):", " ".join(f"{g:.2f}" for g in gaps))
     for c in ctxs:
