@@ -21,6 +21,8 @@ DEPTHS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 
 PRE_MS = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 PACE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
 last_sub = [None]
+RAMP = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+done = [0]
 imgs = np.stack([fixtures.synthetic_blobs(W, H, i) for i in range(B)])
 d = torch.from_numpy(imgs).cuda()
 for nctx in DEPTHS:
@@ -30,11 +32,15 @@ for nctx in DEPTHS:
 
     def run(n, stamps=None, t0=0.0):
         infl = []
+        done[0] = 0
         for i in range(n):
-            c = ctxs[i % nctx] if len(infl) < nctx else None
-            if len(infl) == nctx:
+            depth = nctx if (RAMP <= 0 or stamps is None) else min(nctx, RAMP + done[0])   # RAMP: initial depth, one more per completion
+            free = [x for x in ctxs if x not in infl]
+            c = free[0] if len(infl) < depth else None
+            if len(infl) >= depth:
                 c = infl.pop(0)
                 c.wait()
+                done[0] += 1
                 if stamps is not None:
                     stamps.append(time.perf_counter() - t0)
             if PACE > 0 and last_sub[0] is not None:   # never two submissions closer than PACE ms
@@ -69,7 +75,7 @@ for nctx in DEPTHS:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gaps = np.diff([0.0] + stamps) * 1e3
-        print(f"pace {PACE} ms, contexts {nctx}, {warm} warm-up steps after 0.5 s idle (+ {PRE_MS:.0f} ms of streaming): {K} steps in {dt*1e3:.2f} ms = {dt*1e3/K:.3f} ms/step = {B*K*W*H/dt/1e6:.0f} Mpix/s")
+        print(f"ramp {RAMP}, pace {PACE} ms, contexts {nctx}, {warm} warm-up steps after 0.5 s idle (+ {PRE_MS:.0f} ms of streaming): {K} steps in {dt*1e3:.2f} ms = {dt*1e3/K:.3f} ms/step = {B*K*W*H/dt/1e6:.0f} Mpix/s")
         print("   submit times (ms):", " ".join(f"{s_*1e3:.2f}" for s_ in subs[:8]), "...")
         print("   completion gaps (ms):", " ".join(f"{g:.2f}" for g in gaps))
     for c in ctxs:
