@@ -25,6 +25,9 @@ Added to the contract's JSON line (rank 0; N = 1 unless noted):
                       vector instructions per launch (PMC pass kept under profiles/) / duration against the NOMINAL
                       issue peak (1024 SIMDs x 2.4 GHz / 2 cycles) and against the MEASURED sustained all-CU rate of
                       tools/micro/valu_peak.hip (profiles/valu_peak.json)
+  value_steady_state  (runs of fewer than 150 steps, single rank) the same pipeline over 200 steps after the timed region:
+                      the contract's fences put the pipeline's fill and drain inside the K timed steps (about 2 ms of
+                      the 21 at K = 20)
   latency_ms_single_image   one 1080p image, pageable host pixels -> host results, one context (the C-ABI call under
                       the drop-in RunSIFT)
   value_siftgpu_api_1thread / value_siftgpu_api_threads   the reference's own calling pattern through libsiftgpu.so:
@@ -240,6 +243,17 @@ def main():
                 gathered_first[r] = (gathered["keys"][r][:n0].cpu().numpy().copy(),
                                      gathered["desc"][r][:n0].cpu().numpy().copy())
 
+    # The contract's region holds the pipeline's fill and drain (the fences empty it on both sides): at the driver's 20
+    # steps that is about 2 ms of 21.  The steady-state rate of the same pipeline is reported beside it, from a leg of
+    # its own (single rank only: no collective in an extra leg).
+    steady = None
+    if not use_dist and args.steps < 150:
+        run_steps(nctx, submit_resident)
+        fence()
+        ts = time.perf_counter()
+        run_steps(200, submit_resident)
+        fence()
+        steady = B * 200 * W * H / (time.perf_counter() - ts) / 1e6
     # Legs outside the timed region (rank 0 alone reports them; every rank runs the device ones to stay in step).
     # Roofline leg: per-kernel hipEvent durations are only meaningful when kernels of different streams do not
     # overlap, so the events are recorded in a separate single-stream leg of the same run (same batch, one context).
@@ -326,6 +340,10 @@ def main():
             "value_definition": "driver contract: pixels resident in HBM when the timed region starts, results in host "
                                 "memory when a step ends; value_host_to_host is the same from pinned host pixels (SURVEY 8d)",
         }
+        if steady is not None:
+            out["value_steady_state"] = round(steady, 2)
+            out["value_steady_state_definition"] = ("the same pipeline over 200 steps after the timed region: `value` at "
+                                                    f"{args.steps} steps includes the pipeline's fill and drain between the contract's fences")
         if bound is not None:
             out["config"]["cpu_binding"] = f"{len(bound)} CPUs local to the rank's GPU"
         if prof is not None:

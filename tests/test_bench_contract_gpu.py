@@ -27,6 +27,7 @@ def test_bench_json_line():
     assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 3 * 3 * 1920 * 1080 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
     assert d["value_device_resident"] == d["value"]
+    assert d["value_steady_state"] > 0.8 * d["value"]   # 200 steps of the same pipeline (a 3-step region is mostly fill and drain)
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
