@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""From a rocprofv3 kernel trace of tools/r03_fill_drain.py: for the LAST timed run of a pipeline depth, the device's busy
+"""From a rocprofv3 kernel trace of tools/r03/r03_fill_drain.py: for the LAST timed run of a pipeline depth, the device's busy
 share and the number of distinct batches (descriptor launches delimit them per queue) in 0.5 ms windows.
-   python tools/r03_fd_trace.py <trace dir>"""
+   python tools/r03/r03_fd_trace.py <trace dir>"""
 import csv, glob, sys
 rows = []
 for f in glob.glob(f"{sys.argv[1]}/**/*kernel_trace.csv", recursive=True):

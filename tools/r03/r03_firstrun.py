@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-time costs of a context's first batches: fresh contexts, reserve, then synchronous runs timed one by one."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import fixtures, hessgpu_amd
