@@ -140,7 +140,8 @@ void hess_destroy(hess_ctx* ctx);
 
 /* Replaces PyramidCU::InitPyramid/ResizePyramid/ResizeFeatureStorage (PyramidCU.cpp:113-489)
  * and SiftGPU::AllocatePyramid: pre-allocates pyramids for `batch` images of w*h so that
- * hess_run_* does no allocation (grow-only, like the reference). */
+ * hess_run_* does no allocation (grow-only, like the reference).  It also creates the runtime objects a batch of that
+ * size uses (result copier thread and its DMA queue, the stream's hardware queue): the first batch does not pay for them. */
 int hess_reserve(hess_ctx* ctx, int width, int height, int batch);
 
 /* Replaces SiftGPU::RunSIFT(w,h,data,fmt,type) -> GLTexInput::SetImageData (CUDA branch,
