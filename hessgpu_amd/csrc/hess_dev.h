@@ -133,6 +133,7 @@ struct DescParams {
   int dynamic_indexing;  // -di: theta == 8.0 goes to des[8] (ProgramCU.cu:1755-1759) instead of being dropped
   HostKeypoint* hkeys;   // optional pinned-host mirrors of the packed results (same indexing as keys/desc)
   float* hdesc;
+  int first_image;       // the launch covers images first_image .. first_image + gridDim.y - 1 of the batch
 };
 
 // ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------

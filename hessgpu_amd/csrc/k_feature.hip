@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   __shared__ __attribute__((aligned(16))) float dl[4][128];
   __shared__ __attribute__((aligned(16))) float crow[4][DC_ROWS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y + dp.first_image;  // (a batch's descriptors may be launched in two halves, see enqueue())
   const int ftotal = feat_total[b], ffirst = feat_first[b];
   const long long obase = img_base[b];  // packed output: images of the batch back to back
   const int nwaves = gridDim.x * 4;
@@ -768,6 +768,7 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
                        int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
                        const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
                        float* desc, int cap_feat, int batch) {
+  // (dp.first_image: first image of this launch; `batch` images from there)
   int blocks = (cap_feat + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
