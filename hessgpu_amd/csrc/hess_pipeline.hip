@@ -100,8 +100,11 @@ struct Copier {
   std::string err;
   hipStream_t cs = nullptr;     // copy-only stream (fallback path)
   hipEvent_t ev_done = nullptr; // recorded on the context's stream behind the last kernel of a batch
-  hipEvent_t ev_half = nullptr; // ... behind the descriptor launch of the batch's first images (split > 0)
-  int split = 0;                // the job's results arrive in two parts: images [0, split) first, the rest after ev_done
+  // A batch's descriptors may be launched in up to kMaxParts groups of images; ev_part[k] is recorded behind group k
+  // (the last group's event is ev_done), part_end[k] = first image after group k.  nparts <= 1: one launch.
+  static constexpr int kMaxParts = 4;
+  hipEvent_t ev_part[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+  int nparts = 1, part_end[kMaxParts] = {0, 0, 0, 0};
   // ROCr side (SDMA): agents owning the device / pinned host buffers, engine, completion signal
   bool hsa_ready = false, hsa_failed = false;
   hsa_agent_t gpu_agent{}, cpu_agent{};
@@ -172,7 +175,7 @@ struct hess_ctx {
   bool host_direct = false;        // delivery == kDeliverMirror for the submitted batch
   bool host_fits = false;          // the pinned result buffers hold the worst case of the current plan
   int delivery = kDeliverMirror;   // of the submitted batch (choose_delivery)
-  int split_at = 0;                // the submitted batch's descriptors were launched in two halves at this image (0: one launch)
+  int nparts = 1, part_end[Copier::kMaxParts] = {0, 0, 0, 0};  // the submitted batch's descriptor launches (groups of images)
   int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
   int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
@@ -810,22 +813,26 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.first_image = 0;
   // Delivered by the copier thread, a batch of four or more images gets its descriptors in two launches (the images
   // are independent and packed back to back): the first half's results cross the host link while the second half is
-  // computed -- half of the transfer leaves the batch's critical path (0.27 of 0.53 ms for eight 1080p images).
-  c->split_at = (c->delivery == kDeliverDma && batch >= 4 && c->cp.ev_half && !getenv("HESS_NO_SPLIT")) ? batch / 2 : 0;
+  // computed -- half of the transfer (0.53 ms for eight 1080p images) leaves the batch's critical path.  Four groups
+  // shorten a lone batch a little more (1.75 / 1.58 / 1.53 ms for 1 / 2 / 4) but cost the pipelined rate 1 %:
+  // HESS_DESC_PARTS=n overrides (1: one launch, up to kMaxParts).
+  {
+    int want = batch >= 4 ? 2 : 1;
+    if (const char* e = getenv("HESS_DESC_PARTS")) want = std::max(1, std::min<int>(Copier::kMaxParts, std::min(batch, atoi(e))));
+    if (c->delivery != kDeliverDma || !c->cp.ev_part[0]) want = 1;
+    c->nparts = want;
+    for (int k = 0; k < want; k++) c->part_end[k] = (int)((long long)batch * (k + 1) / want);
+  }
   {
     ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
-    auto launch = [&](int first, int count) {
+    int first = 0;
+    for (int k = 0; k < c->nparts; k++) {
       dsp.first_image = first;
       launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                         (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
-                        (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, count);
-    };
-    if (c->split_at > 0) {
-      launch(0, c->split_at);
-      HIP_TRY(c, hipEventRecord(c->cp.ev_half, st));
-      launch(c->split_at, batch - c->split_at);
-    } else {
-      launch(0, batch);
+                        (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, c->part_end[k] - first);
+      if (k < c->nparts - 1) HIP_TRY(c, hipEventRecord(c->cp.ev_part[k], st));
+      first = c->part_end[k];
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev[7], st));
@@ -940,7 +947,7 @@ int enqueue_user(hess_ctx* c) {
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
   dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   dsp.first_image = 0;
-  c->split_at = 0;
+  c->nparts = 1;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
@@ -1076,17 +1083,16 @@ void copier_main(hess_ctx* c) {
       snprintf(msg, sizeof(msg), "%s failed: %s (copier)", what, hipGetErrorString(e));
       rc = e == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;
     };
-    // Two parts when the batch's descriptors were launched in two halves (split > 0): the first images' results cross
-    // while the second launch computes; else one part behind the last kernel.  The counts (and the overflow words)
-    // are in the pinned count block since feature_scan_kernel, i.e. before either event.
-    const int split = cp.split;
-    hipError_t e = hipEventSynchronize(split > 0 ? cp.ev_half : cp.ev_done);
+    // Several parts when the batch's descriptors were launched in groups of images (nparts > 1): a group's results
+    // cross while the next group is computed; else one part behind the last kernel.  The counts (and the overflow
+    // words) are in the pinned count block since feature_scan_kernel, i.e. before any of the events.
+    const int nparts = cp.nparts > 1 ? cp.nparts : 1;
+    hipError_t e = hipEventSynchronize(nparts > 1 ? cp.ev_part[0] : cp.ev_done);
     if (e != hipSuccess) fail("hipEventSynchronize", e);
     if (!rc) {
       const int* hs = (const int*)c->h_small.p;
       overflow = hs[batch + 1] != 0 || hs[batch + 2] != 0;
       const size_t total = overflow ? 0 : (size_t)hs[batch];
-      const size_t n1 = (split > 0 && !overflow) ? (size_t)hs[split] : 0;  // features of images [0, split)
       DevBuf *hk = &c->h_keys, *hd = &c->h_desc;
       if (total) {
         // (the pinned buffers hold the worst case unless that exceeds 512 MB: then they grow here, rarely)
@@ -1108,11 +1114,13 @@ void copier_main(hess_ctx* c) {
           fail("hipMemcpyAsync(desc)", e);
         if (!rc && (e = hipStreamSynchronize(cp.cs)) != hipSuccess) fail("hipStreamSynchronize(copy stream)", e);
       };
-      if (split > 0) {
-        copy_part(0, n1);
-        if ((e = hipEventSynchronize(cp.ev_done)) != hipSuccess) fail("hipEventSynchronize", e);
+      size_t done_feats = 0;
+      for (int k = 0; k < nparts; k++) {
+        if (k > 0 && (e = hipEventSynchronize(k < nparts - 1 ? cp.ev_part[k] : cp.ev_done)) != hipSuccess) fail("hipEventSynchronize", e);
+        const size_t upto = overflow ? 0 : (k < nparts - 1 ? (size_t)hs[cp.part_end[k]] : total);  // features of the images so far
+        copy_part(done_feats, upto - done_feats);
+        done_feats = upto;
       }
-      copy_part(n1, total - n1);
     }
     lk.lock();
     cp.rc = rc;
@@ -1129,7 +1137,7 @@ int copier_start(hess_ctx* c) {
   if (cp.started) return 0;
   HIP_TRY(c, hipStreamCreateWithFlags(&cp.cs, hipStreamNonBlocking));
   HIP_TRY(c, hipEventCreateWithFlags(&cp.ev_done, hipEventDisableTiming));
-  HIP_TRY(c, hipEventCreateWithFlags(&cp.ev_half, hipEventDisableTiming));
+  for (hipEvent_t& ev : cp.ev_part) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   try {
     cp.th = std::thread(copier_main, c);
   } catch (...) {
@@ -1155,7 +1163,7 @@ void copier_stop(hess_ctx* c) {
   if (cp.hsa_ready) { (void)hsa_signal_destroy(cp.sig); cp.hsa_ready = false; }
   if (cp.cs) { (void)hipStreamDestroy(cp.cs); cp.cs = nullptr; }
   if (cp.ev_done) { (void)hipEventDestroy(cp.ev_done); cp.ev_done = nullptr; }
-  if (cp.ev_half) { (void)hipEventDestroy(cp.ev_half); cp.ev_half = nullptr; }
+  for (hipEvent_t& ev : cp.ev_part) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
 }
 
 // How the results of a batch of `batch` images reach the host (see the kDeliver* comment): small batches through the
@@ -1188,7 +1196,8 @@ int submit_impl(hess_ctx* c, const PendingRun& r) {
     HIP_TRY(c, hipEventRecord(cp.ev_done, c->st));
     std::lock_guard<std::mutex> lk(cp.mu);
     cp.batch = r.batch;
-    cp.split = c->split_at;
+    cp.nparts = c->nparts;
+    for (int k = 0; k < Copier::kMaxParts; k++) cp.part_end[k] = c->part_end[k];
     cp.done = false;
     cp.has_job = true;
     cp.cv.notify_all();

@@ -259,19 +259,20 @@ def test_result_delivery_modes(gpu_ctx_factory, monkeypatch, mode):
     _compare_all(g, o, imgs[1:], f"{mode} delivery, batch of 2", stages=False)
 
 
-@pytest.mark.parametrize("nosplit", [False, True])
-def test_two_part_delivery_of_larger_batches(gpu_ctx_factory, monkeypatch, nosplit):
-    """Batches of four or more images delivered by the copier thread get their descriptors in two launches, the
-    first half's results crossing the host link while the second half is computed (hess_pipeline.hip, enqueue();
-    HESS_NO_SPLIT=1: one launch, one transfer).  Same results, also when one half -- or a single image -- has no
-    features at all, and for an odd batch."""
-    if nosplit:
-        monkeypatch.setenv("HESS_NO_SPLIT", "1")
+@pytest.mark.parametrize("parts", [None, "1", "2", "3"])
+def test_delivery_in_parts_of_larger_batches(gpu_ctx_factory, monkeypatch, parts):
+    """Batches of four or more images delivered by the copier thread get their descriptors in several launches
+    (groups of images), a group's results crossing the host link while the next group is computed
+    (hess_pipeline.hip, enqueue(); HESS_DESC_PARTS=n overrides the number of groups, 1 = one launch, one transfer).
+    Same results, also when a group -- or a single image -- has no features at all, and for an odd batch."""
+    if parts:
+        monkeypatch.setenv("HESS_DESC_PARTS", parts)
     g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
     o = OracleSession(threads=8, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
     blobs = [fixtures.synthetic_blobs(320, 240, 70 + i) for i in range(5)]
     flat = np.full((240, 320), 128, np.uint8)
     _compare_all(g, o, np.stack(blobs), "batch of 5", stages=False)
+    _compare_all(g, o, np.stack(blobs + blobs[:3]), "batch of 8", stages=False)
     n = _compare_all(g, o, np.stack([flat, flat, blobs[0], blobs[1]]), "first half without features", stages=False)
     assert n[0] == 0 and n[1] == 0 and n[2] > 0
     n = _compare_all(g, o, np.stack([blobs[2], blobs[3], flat, flat, flat]), "second half without features", stages=False)
