@@ -577,6 +577,12 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
             s_oct = k["s"].astype(np.float64) / (2.0 ** (k["level"] // 3))
             fbytes += float(np.sum((15.0 * s_oct) ** 2 * 8.0 + 16.0 + 24.0 + 512.0))
             nfeat += len(k)
+        # (a batch of four or more images delivered by the copier thread has its descriptors in two launches, each over
+        # half of the images: per-launch figures are per kernel launch, as a kernel trace counts them)
+        per_step = max(1, round(d["launches"] / steps))
+        fbytes_step = fbytes
+        fbytes /= per_step
+        nfeat = int(round(nfeat / per_step))
         dur = d["ms"] * 1e-3 / d["launches"]
         achieved = fbytes / dur / 1e9
         names = {False: "descriptor_kernel<false> (one wavefront per feature: rotated-grid histogram + normalisation + packed "
@@ -589,7 +595,8 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profile_value("descriptor_counters.json", "hbm_bytes_per_launch"),
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1),
-            "features_per_launch": nfeat, "launches": d["launches"], "ms_per_step": round(d["ms"] / steps, 4),
+            "features_per_launch": nfeat, "launches": d["launches"], "launches_per_step": per_step,
+            "ms_per_step": round(d["ms"] / steps, 4),
         }
         insts = _profile_value("descriptor_counters.json", "valu_insts_per_feature")
         if insts:
@@ -598,8 +605,10 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
         dd = (prof_other or {}).get("descriptor")
         if dd and dd["launches"]:
             ddur = dd["ms"] * 1e-3 / dd["launches"]
+            dbytes = fbytes_step / max(1, round(dd["launches"] / steps))
             e["without_host_mirror" if mirror else "with_host_mirror"] = {
-                "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(fbytes / ddur / 1e9, 1), "unit": "GB/s",
+                "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(dbytes / ddur / 1e9, 1), "unit": "GB/s",
+                "launches_per_step": max(1, round(dd["launches"] / steps)),
                 "kernel": "descriptor_kernel<false>" if mirror else "descriptor_kernel<true>",
                 "note": "same launch on a context created with HESS_DELIVERY=" + ("dma" if mirror else "mirror") +
                         ": descriptor_kernel<true> also stores keypoints + descriptors into pinned host memory and, "

@@ -824,9 +824,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     for (int k = 0; k < want; k++) c->part_end[k] = (int)((long long)batch * (k + 1) / want);
   }
   {
-    ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);
     int first = 0;
     for (int k = 0; k < c->nparts; k++) {
+      ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);  // (per launch, so that the counts agree with a kernel trace)
       dsp.first_image = first;
       launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                         (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
