@@ -180,6 +180,8 @@ struct hess_ctx {
   int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
+  bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
+  int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
   Copier cp;
   Stager sg;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
@@ -675,7 +677,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // T(o, l) = 3o + l is the earliest step of level l of octave o (level 0 of octave o+1 is the decimated level_ds of
   // octave o): the top level of an octave and level 1 of the next are due together and independent, so they share a
   // launch (launch_gauss_pair) -- one launch fewer per octave in the dependent chain.
-  const bool pair_levels = fused_decim && s.level_ds < s.level_max && s.level_max >= 2 && !getenv("HESS_NO_PAIR");
+  const bool pair_levels = fused_decim && s.level_ds < s.level_max && s.level_max >= 2 && !c->no_pair;
   int deferred_o = -1;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
@@ -818,7 +820,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // HESS_DESC_PARTS=n overrides (1: one launch, up to kMaxParts).
   {
     int want = batch >= 4 ? 2 : 1;
-    if (const char* e = getenv("HESS_DESC_PARTS")) want = std::max(1, std::min<int>(Copier::kMaxParts, std::min(batch, atoi(e))));
+    if (c->desc_parts > 0) want = std::max(1, std::min<int>(Copier::kMaxParts, std::min(batch, c->desc_parts)));
     if (c->delivery != kDeliverDma || !c->cp.ev_part[0]) want = 1;
     c->nparts = want;
     for (int k = 0; k < want; k++) c->part_end[k] = (int)((long long)batch * (k + 1) / want);
@@ -1347,6 +1349,8 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   }
   if (const char* m = getenv("HESS_MIRROR_MAX_BATCH")) c->mirror_max_batch = atoi(m);
   if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
+  c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
+  if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
   return c;
 }
 
