@@ -282,6 +282,34 @@ def test_delivery_in_parts_of_larger_batches(gpu_ctx_factory, monkeypatch, parts
     _compare_all(g, o, np.stack(blobs[:3]), "back to a batch of 3 (one launch)", stages=False)
 
 
+@pytest.mark.parametrize("side", [True, False])
+def test_pinned_input_is_uploaded_beside_the_queues(gpu_ctx_factory, monkeypatch, side):
+    """hess_submit_host with pinned pixels and a batch the copier thread delivers: the upload is an SDMA copy started by
+    the caller, the copier thread waits for it on the host and enqueues the kernels (no transfer command in the
+    context's hardware queue; HESS_NO_SIDE_UPLOAD=1: a copy on the stream as before).  Same results as the oracle
+    and as pageable input, also after an overflow that re-runs the batch, for several batches in a row and for a
+    batch of two (in-kernel delivery: upload on the stream)."""
+    import torch
+    if not side:
+        monkeypatch.setenv("HESS_NO_SIDE_UPLOAD", "1")
+    monkeypatch.setenv("HESS_INITIAL_CAP", "64")     # the first batches overflow and are run again from the device copy
+    g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=400)
+    monkeypatch.delenv("HESS_INITIAL_CAP")
+    o = OracleSession(threads=8, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=400)
+    for nimg, seed in ((5, 0), (8, 20), (2, 40), (5, 60)):
+        imgs = np.stack([fixtures.synthetic_blobs(320, 240, seed + i) for i in range(nimg)])
+        pinned = torch.from_numpy(imgs).pin_memory()
+        g.submit_host(ptr=pinned.data_ptr(), batch=nimg, height=240, width=320)
+        g.wait()
+        want = o.run(imgs)
+        assert [g.count(b) for b in range(nimg)] == want and sum(want) > 0
+        for b in range(nimg):
+            gk, gd = g.fetch(b)
+            ok, od = o.fetch(b)
+            assert gk.tobytes() == ok.tobytes() and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (nimg, b)
+    assert g.regrown() >= 1
+
+
 def test_result_delivery_default_switches_with_batch_size(gpu_ctx_factory):
     """Default policy: batches of one or two images use the in-kernel mirror, larger ones the copier thread; a context
     that alternates between them (and pipelines submit/wait pairs) keeps delivering the oracle's results."""
