@@ -27,9 +27,11 @@ def digest(c, B):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    host = len(sys.argv) > 2 and sys.argv[2] == "host"   # pinned host pixels (hess_submit_host: upload beside the queues, kernels enqueued by the copier thread)
     B, W, H = 8, 1920, 1080
     imgs = np.stack([fixtures.synthetic_blobs(W, H, i) for i in range(4)] * 2)
     d = torch.from_numpy(imgs).to("cuda:0")
+    pinned = torch.from_numpy(imgs).pin_memory()
     ctxs = [hessgpu_amd.HessContext(0, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=4096) for _ in range(3)]
     ref = None
     inflight = []
@@ -42,13 +44,16 @@ def main():
             dg = digest(f, B)
             ref = ref or dg
             bad += dg != ref
-        c.submit_device(d.data_ptr(), B, H, W)
+        if host:
+            c.submit_host(ptr=pinned.data_ptr(), batch=B, height=H, width=W)
+        else:
+            c.submit_device(d.data_ptr(), B, H, W)
         inflight.append(c)
     while inflight:
         f = inflight.pop(0)
         f.wait()
         bad += digest(f, B) != ref
-    print(f"soak: {n} pipelined batches of {B} images, {bad} differ from the first")
+    print(f"soak: {n} pipelined batches of {B} images ({'pinned host' if host else 'device-resident'} pixels), {bad} differ from the first")
     sys.exit(1 if bad else 0)
 
 
