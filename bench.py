@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")
     ap.add_argument("--no-api-leg", action="store_true", help="skip the libsiftgpu.so (RunSIFT + GetFeatureVector) legs")
     ap.add_argument("--no-configs4", action="store_true", help="skip the 4096x4096 leg (BASELINE.json configs[4])")
+    ap.add_argument("--no-steady", action="store_true", help="skip the 200-step steady-state leg that follows a timed region of "
+                    "fewer than 150 steps (counter passes: every launch of the run is then one of warmup + steps + profile leg)")
     ap.add_argument("--api-threads", type=int, default=8, help="SiftGPU instances (host threads) of the multi-instance leg")
     ap.add_argument("--gather-dest", choices=("shm", "host", "hbm"), default="shm",
                     help="N > 1: where rank 0 finds the feature lists of the global batch after the RCCL gather: shm = "
@@ -247,7 +249,7 @@ def main():
     # steps that is about 2 ms of 21.  The steady-state rate of the same pipeline is reported beside it, from a leg of
     # its own (single rank only: no collective in an extra leg).
     steady = None
-    if not use_dist and args.steps < 150:
+    if not use_dist and args.steps < 150 and not args.no_steady:
         run_steps(nctx, submit_resident)
         fence()
         ts = time.perf_counter()
@@ -355,6 +357,11 @@ def main():
             if len(ranked) > 1:
                 out["roofline_secondary"] = ranked[1]
             out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"] and k != "gauss_octave0"}
+            # the dominant kernel of the committed kernel trace (top row of the rocprofv3 statistics of the last profiled
+            # round), priced with the bytes of that profiled run: a copy, so that the line and the trace name the same kernel
+            top = _profile_json("kernel_stats_top.json")
+            if top:
+                out["roofline_by_rocprof"] = top
         if host is not None:
             out.update(host)
         if api is not None:
@@ -371,6 +378,10 @@ def main():
                 out["parity_checked_ranks"] = 1 + len(gathered_first)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(imgs[:min(nd, 4)])
+        bad = bad_fractions(out)
+        if bad:   # say so on the line itself rather than print an impossible number unmarked
+            out["consistency_error"] = [f"{w} = {v}: not a fraction of its peak" for w, v in bad]
+            print("bench.py: inconsistent roofline entries:", out["consistency_error"], file=sys.stderr)
         if json_fd is None:
             print(json.dumps(out), flush=True)
         else:
@@ -618,13 +629,35 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
     return out
 
 
-def _profile_value(name, key):
-    """A number from a committed PMC summary under profiles/, if one exists."""
+def _profile_json(name):
+    """A committed summary under profiles/, if it exists."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f).get(key)
+            return json.load(f)
     except Exception:
         return None
+
+
+def _profile_value(name, key):
+    """A number from a committed PMC summary under profiles/, if one exists."""
+    return (_profile_json(name) or {}).get(key)
+
+
+def bad_fractions(node, path=""):
+    """Every frac / frac_of_* on the line that is not in (0, 1]: a fraction of a peak above 1 is a bookkeeping error
+    (round 3 published 15.94), never a measurement."""
+    bad = []
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k in ("frac", "frac_of_measured", "frac_of_mix"):
+                if v is not None and not (0.0 < v <= 1.0):
+                    bad.append((path + "/" + k, v))
+            else:
+                bad += bad_fractions(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            bad += bad_fractions(v, f"{path}[{i}]")
+    return bad
 
 
 def _host_cores():

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,7 +98,7 @@ struct Copier {
   int batch = 0;
   int rc = 0;            // result of the last job (hess_status)
   bool overflow = false; // the batch overflowed its feature storage: nothing was copied
-  std::string err;
+  char err[320] = "";    // message of the last failed job (a fixed array: the copier thread must not throw)
   hipStream_t cs = nullptr;     // copy-only stream (fallback path)
   hipEvent_t ev_done = nullptr; // recorded on the context's stream behind the last kernel of a batch
   // A batch's descriptors may be launched in up to kMaxParts groups of images; ev_part[k] is recorded behind group k
@@ -168,7 +169,9 @@ struct hess_ctx {
   bool zero_filled = false;  // the running batch's det-H launch has cleared `zeroed`
   struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist;
   // host results
-  int batch = 0;
+  int batch = 0;          // images whose results the context holds (0 after a failed or while a pending run: hess_count /
+                          // hess_fetch / hess_device_results refuse instead of handing out the run before)
+  int pyramid_batch = 0;  // images whose pyramid is resident (hess_run_keypoints on the current image)
   std::vector<int> counts;
   std::vector<size_t> offs;
   DevBuf h_keys, h_desc, h_small;  // pinned
@@ -228,7 +231,7 @@ void set_err(hess_ctx* c, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  c->err = buf;
+  try { c->err = buf; } catch (...) {}  // (nothing thrown crosses the C ABI; the message is then the previous one)
   if (c->p.verbose & 1) fprintf(stderr, "hessgpu: %s\n", buf);
 }
 
@@ -1051,11 +1054,54 @@ bool copier_hsa_setup(hess_ctx* c) {
   return true;
 }
 
-// keys + descriptors of features [first, first + total) to the pinned host buffers by SDMA; false: ROCr refused, use
-// the fallback
-bool copier_hsa_copy(hess_ctx* c, size_t first, size_t total) {
+// Host wait for a copy's completion signal to drop below `below`, in slices of a second up to HESS_COPY_TIMEOUT_S
+// (default 10): a lost completion must not hang hess_wait / hess_destroy (the reference returns 0 on device errors,
+// SiftPyramid.h:162-163, it never hangs).  Returns 0 when the copies completed, 1 when the limit expired, 2 when ROCr
+// reported a failed copy (it then leaves a NEGATIVE value in the signal); *last = the value seen.
+// HESS_COPIER_FAULT=timeout|error makes the next wait of the process report that outcome (fault injection for the
+// tests; the real signal is still waited for, so nothing is left in flight).
+std::atomic<int> g_copier_fault{-1};  // -1: not read yet, 0: none, 1: timeout, 2: error (consumed by the first wait)
+int wait_copy_signal(hsa_signal_t sig, hsa_signal_value_t below, hsa_signal_value_t* last, bool injectable = true) {
+  static const double limit_s = [] { const char* e = getenv("HESS_COPY_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 10.0; }();
+  static const uint64_t ticks_per_s = [] {
+    uint64_t f = 0;
+    return (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &f) == HSA_STATUS_SUCCESS && f) ? f : (uint64_t)100000000;
+  }();
+  int inject = injectable ? g_copier_fault.load() : 0;
+  if (injectable && inject < 0) {
+    const char* e = getenv("HESS_COPIER_FAULT");
+    int want = !e ? 0 : (!strcmp(e, "timeout") ? 1 : (!strcmp(e, "error") ? 2 : 0));
+    int expect = -1;
+    if (!g_copier_fault.compare_exchange_strong(expect, want)) want = expect;
+    inject = want;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  hsa_signal_value_t v;
+  for (;;) {
+    v = hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, below, ticks_per_s, HSA_WAIT_STATE_BLOCKED);
+    if (v < below) break;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) { if (last) *last = v; return 1; }
+  }
+  if (last) *last = v;
+  if (inject > 0) {
+    int expect = inject;
+    if (g_copier_fault.compare_exchange_strong(expect, 0)) return inject;
+  }
+  return v < 0 ? 2 : 0;
+}
+
+// keys + descriptors of features [first, first + total) to the pinned host buffers by SDMA.  0: done; 1: ROCr refused
+// to take the copy, use the fallback; 2: a copy was taken and did not complete (timeout or error, `why`): the batch fails.
+int copier_hsa_copy(hess_ctx* c, size_t first, size_t total, char* why, size_t why_len) {
   Copier& cp = c->cp;
   const int ncopy = c->dim ? 2 : 1;
+  hsa_signal_value_t seen = 0;
+  auto lost = [&](int w) {
+    snprintf(why, why_len, "device->host copy of the results %s (signal value %lld, engine 0x%x)",
+             w == 1 ? "did not complete in time" : "failed", (long long)seen, cp.engine);
+    cp.hsa_ready = false; cp.hsa_failed = true;  // later batches take the stream copy; the signal is not reused
+    return 2;
+  };
   hsa_signal_store_relaxed(cp.sig, ncopy);
   auto one = [&](void* dst, const void* src, size_t bytes) {
     hsa_status_t st = cp.engine
@@ -1068,14 +1114,14 @@ bool copier_hsa_copy(hess_ctx* c, size_t first, size_t total) {
   };
   if (!one((char*)c->h_keys.p + first * sizeof(HostKeypoint), (const char*)c->keys.p + first * sizeof(HostKeypoint),
            total * sizeof(HostKeypoint)))
-    return false;
+    return 1;
   if (c->dim && !one((char*)c->h_desc.p + first * c->dim * 4, (const char*)c->desc.p + first * c->dim * 4, total * c->dim * 4)) {
-    // the first copy is in flight and will decrement the signal once: wait for it, then report failure
-    while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, ncopy, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= ncopy) {}
-    return false;
+    // the first copy is in flight and will decrement the signal once: wait for it, then take the fallback for both
+    if (const int w = wait_copy_signal(cp.sig, ncopy, &seen)) return lost(w);
+    return 1;
   }
-  while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
-  return true;
+  if (const int w = wait_copy_signal(cp.sig, 1, &seen)) return lost(w);
+  return 0;
 }
 
 void copier_main(hess_ctx* c) {
@@ -1097,14 +1143,28 @@ void copier_main(hess_ctx* c) {
     hipError_t e = hipSuccess;
     if (cp.upload_first) {  // wait for the pixels on the host, then enqueue the batch
       const auto t0 = std::chrono::steady_clock::now();
-      while (hsa_signal_wait_scacquire(cp.sig_in, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+      hsa_signal_value_t seen = 0;
+      if (const int w = wait_copy_signal(cp.sig_in, 1, &seen)) {
+        // the pixels never arrived (or arrived wrong): the kernels are NOT run on them
+        snprintf(msg, sizeof(msg), "host->device upload of the pixels %s (signal value %lld) (copier)",
+                 w == 1 ? "did not complete in time" : "failed", (long long)seen);
+        rc = HESS_ERR_DEVICE;
+        cp.have_sig_in = false;  // (a signal that may still be written is left alone, not reused)
+      }
       PendingRun& r = *cp.run;
       r.t_load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
-      if (!rc && (e = hipEventRecord(cp.ev_done, c->st)) != hipSuccess) fail("hipEventRecord", e);
-      if (rc && !msg[0]) snprintf(msg, sizeof(msg), "%s", c->err.c_str());
-      cp.nparts = c->nparts;
-      for (int k = 0; k < Copier::kMaxParts; k++) cp.part_end[k] = c->part_end[k];
+      cp.nparts = 1;
+      if (!rc) {
+        try {
+          rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
+        } catch (...) { rc = HESS_ERR_NOMEM; snprintf(msg, sizeof(msg), "out of host memory (copier)"); }
+        if (!rc && (e = hipEventRecord(cp.ev_done, c->st)) != hipSuccess) fail("hipEventRecord", e);
+        if (rc && !msg[0]) snprintf(msg, sizeof(msg), "%s", c->err.c_str());
+        if (!rc) {  // (a half-run enqueue leaves no parts to wait for)
+          cp.nparts = c->nparts;
+          for (int k = 0; k < Copier::kMaxParts; k++) cp.part_end[k] = c->part_end[k];
+        }
+      }
     }
     // Several parts when the batch's descriptors were launched in groups of images (nparts > 1): a group's results
     // cross while the next group is computed; else one part behind the last kernel.  The counts (and the overflow
@@ -1127,7 +1187,11 @@ void copier_main(hess_ctx* c) {
       }
       auto copy_part = [&](size_t first, size_t n) {
         if (rc || !n) return;
-        if (copier_hsa_setup(c) && copier_hsa_copy(c, first, n)) return;  // both blocks are in host memory
+        if (copier_hsa_setup(c)) {
+          const int hr = copier_hsa_copy(c, first, n, msg, sizeof(msg));
+          if (hr == 0) return;  // both blocks are in host memory
+          if (hr == 2) { rc = HESS_ERR_DEVICE; return; }
+        }
         const size_t kb = sizeof(HostKeypoint), db = (size_t)c->dim * 4;
         if ((e = hipMemcpyAsync((char*)hk->p + first * kb, (const char*)c->keys.p + first * kb, n * kb, hipMemcpyDeviceToHost, cp.cs)) != hipSuccess)
           fail("hipMemcpyAsync(keys)", e);
@@ -1147,7 +1211,7 @@ void copier_main(hess_ctx* c) {
     lk.lock();
     cp.rc = rc;
     cp.overflow = overflow;
-    cp.err = msg;
+    snprintf(cp.err, sizeof(cp.err), "%s", msg);
     cp.has_job = false;
     cp.done = true;
     cp.cv.notify_all();
@@ -1202,7 +1266,7 @@ void choose_delivery(hess_ctx* c, int batch) {
 
 // Enqueue the whole path (the per-image counts reach the pinned count block by feature_scan_kernel's own stores);
 // returns without waiting.
-int submit_impl(hess_ctx* c, const PendingRun& r) {
+int submit_inner(hess_ctx* c, const PendingRun& r) {
   if (!c->user_keys.empty() && r.batch != 1) {
     set_err(c, "a keypoint list applies to a single image");
     return HESS_ERR_ARG;
@@ -1229,10 +1293,20 @@ int submit_impl(hess_ctx* c, const PendingRun& r) {
   return 0;
 }
 
+// (nothing thrown crosses the C ABI: enqueue_user builds host vectors)
+int submit_impl(hess_ctx* c, const PendingRun& r) {
+  try {
+    return submit_inner(c, r);
+  } catch (...) {
+    set_err(c, "out of host memory while preparing the batch");
+    return HESS_ERR_NOMEM;
+  }
+}
+
 // Wait for the submitted batch, grow storage and re-run if a list overflowed; with kDeliverBlit bring the
 // keypoints and descriptors of the whole batch to the host with one transfer each (the other modes have
 // delivered them by now).
-int wait_impl(hess_ctx* c, const PendingRun& r) {
+int wait_inner(hess_ctx* c, const PendingRun& r) {
   int rc;
   int* hs = (int*)c->h_small.p;
   const int batch = r.batch;
@@ -1241,7 +1315,7 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
       Copier& cp = c->cp;
       std::unique_lock<std::mutex> lk(cp.mu);
       cp.cv.wait(lk, [&] { return cp.done; });
-      if (cp.rc) { c->err = cp.err; return cp.rc; }
+      if (cp.rc) { set_err(c, "%s", cp.err); return cp.rc; }
     } else {
       HIP_TRY(c, hipStreamSynchronize(c->st));
     }
@@ -1258,7 +1332,6 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
     if ((rc = submit_impl(c, r))) return rc;
   }
   drain_profile(c);
-  c->batch = batch;
   c->counts.resize(batch);
   c->offs.assign(batch + 1, 0);
   for (int b = 0; b < batch; b++) {
@@ -1310,7 +1383,18 @@ int wait_impl(hess_ctx* c, const PendingRun& r) {
     c->timing[HESS_T_DESCRIPTOR] = el(6, 7);
   }
   c->timing[HESS_T_TOTAL] = el(0, 7) + c->timing[HESS_T_LOAD];
+  c->batch = c->pyramid_batch = batch;  // only now: every error return above leaves the context without results
   return 0;
+}
+
+int wait_impl(hess_ctx* c, const PendingRun& r) {
+  try {
+    return wait_inner(c, r);
+  } catch (...) {  // the host-side count / keypoint-list vectors
+    c->user_keys.clear();
+    set_err(c, "out of host memory while collecting the results");
+    return HESS_ERR_NOMEM;
+  }
 }
 
 }  // namespace
@@ -1426,11 +1510,10 @@ static int prime(hess_ctx* c, int batch) {
             ? hsa_amd_memory_async_copy_on_engine(dst, cp.cpu_agent, src, cp.gpu_agent, 64, 0, nullptr, cp.sig,
                                                   (hsa_amd_sdma_engine_id_t)cp.engine, false)
             : hsa_amd_memory_async_copy(dst, cp.cpu_agent, src, cp.gpu_agent, 64, 0, nullptr, cp.sig);
-        if (st == HSA_STATUS_SUCCESS)
-          while (hsa_signal_wait_scacquire(cp.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+        if (st == HSA_STATUS_SUCCESS && wait_copy_signal(cp.sig, 1, nullptr, false) != 0) { cp.hsa_ready = false; cp.hsa_failed = true; }
       };
       tiny(c->h_keys.p, c->keys.p);
-      if (c->dim && c->desc.p && c->h_desc.p && c->h_desc.bytes >= 64) tiny(c->h_desc.p, c->desc.p);
+      if (cp.hsa_ready && c->dim && c->desc.p && c->h_desc.p && c->h_desc.bytes >= 64) tiny(c->h_desc.p, c->desc.p);
     }
   }
   if (c->zeroed.p && c->zeroed.bytes >= 64) {
@@ -1465,7 +1548,8 @@ int hess_submit_device(hess_ctx* c, const void* dev_pixels, int width, int heigh
   if (rc) return rc;
   if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!c->pend) c->pend = new PendingRun();
+  c->batch = c->pyramid_batch = 0;  // the results and the pyramid of the run before are gone from here on
+  if (!c->pend && !(c->pend = new (std::nothrow) PendingRun())) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
   *c->pend = PendingRun{dev_pixels, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, false};
   rc = submit_impl(c, *c->pend);
   if (rc) return rc;
@@ -1499,6 +1583,8 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
   if (rc) return rc;
   if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
+  c->batch = c->pyramid_batch = 0;  // the results and the pyramid of the run before are gone from here on
+  if (!c->pend && !(c->pend = new (std::nothrow) PendingRun())) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
   const size_t bytes = (size_t)(batch - 1) * image_stride + (size_t)height * pitch;
   rc = ensure(c, c->stage, bytes + 16);
   if (rc) return rc;
@@ -1524,7 +1610,6 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
       hsa_signal_store_relaxed(cp.sig_in, 1);
       if (hsa_amd_memory_async_copy(c->stage.p, cp.gpu_agent, pixels, pi.agentOwner, bytes, 0, nullptr, cp.sig_in) == HSA_STATUS_SUCCESS) {
         c->last_input_bytes = bytes;
-        if (!c->pend) c->pend = new PendingRun();
         *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, false};
         {
           std::lock_guard<std::mutex> lk(cp.mu);
@@ -1591,7 +1676,6 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
   }
   HIP_TRY(c, hipEventRecord(c->ev_load[1], c->st));
   c->last_input_bytes = bytes;
-  if (!c->pend) c->pend = new PendingRun();
   *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, true};
   rc = submit_impl(c, *c->pend);
   if (rc) return rc;
@@ -1617,7 +1701,9 @@ int hess_last_input(hess_ctx* c, void* out, size_t bytes) {
 
 int hess_set_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
   if (!c || num < 0 || (num > 0 && !keys)) return HESS_ERR_ARG;
-  c->user_keys.assign(keys, keys + num);
+  try {
+    c->user_keys.assign(keys, keys + num);
+  } catch (...) { c->user_keys.clear(); set_err(c, "out of host memory"); return HESS_ERR_NOMEM; }
   c->user_have_orientation = keys_have_orientation != 0;
   c->user_on_current = false;
   return 0;
@@ -1625,26 +1711,35 @@ int hess_set_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys
 
 int hess_run_keypoints(hess_ctx* c, const hess_keypoint* keys, int num, int keys_have_orientation) {
   if (!c || num <= 0 || !keys) return HESS_ERR_ARG;
-  if (!c->planned || c->batch < 1) { set_err(c, "no current image: run an image first"); return HESS_ERR_STATE; }
+  if (!c->planned || c->pyramid_batch < 1) { set_err(c, "no current image: run an image first"); return HESS_ERR_STATE; }
   if (c->pend && c->pend->active) { set_err(c, "a submitted batch is still pending: call hess_wait first"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
-  c->user_keys.assign(keys, keys + num);
+  try {
+    c->user_keys.assign(keys, keys + num);
+  } catch (...) { c->user_keys.clear(); set_err(c, "out of host memory"); return HESS_ERR_NOMEM; }
   c->user_have_orientation = keys_have_orientation != 0;
   c->user_on_current = true;
-  if (!c->pend) c->pend = new PendingRun();
+  if (!c->pend) { c->user_keys.clear(); set_err(c, "no current image"); return HESS_ERR_STATE; }
   PendingRun r = *c->pend;  // geometry of the current image
   if (r.width <= 0) { c->user_keys.clear(); set_err(c, "no current image"); return HESS_ERR_STATE; }
   r.batch = 1;
   r.t_load_ms = 0.0;
+  const int keep_pyramid = c->pyramid_batch;
+  c->batch = 0;  // results of the run before: gone; the pyramid stays (that is the point of this entry)
   int rc = submit_impl(c, r);
   if (rc) { c->user_keys.clear(); return rc; }
-  return wait_impl(c, r);
+  rc = wait_impl(c, r);
+  c->pyramid_batch = keep_pyramid;
+  if (rc) c->user_keys.clear();
+  return rc;
 }
 
 int hess_debug_key_levels(hess_ctx* c, const int* levels, int num) {
   if (!c || num < 0) return HESS_ERR_ARG;
   c->user_levels.clear();
-  if (levels && num > 0) c->user_levels.assign(levels, levels + num);
+  try {
+    if (levels && num > 0) c->user_levels.assign(levels, levels + num);
+  } catch (...) { c->user_levels.clear(); set_err(c, "out of host memory"); return HESS_ERR_NOMEM; }
   return 0;
 }
 

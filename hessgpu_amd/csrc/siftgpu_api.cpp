@@ -197,10 +197,19 @@ void collect_results(SiftGPU* self) {
 // Bring the results of the last run into the instance's own arrays (before the context goes away, or for SaveSIFT).
 void materialize_results(Impl* im) {
   if (!im->results_in_ctx || !im->ctx) return;
-  im->keys.resize(im->nfeat ? im->nfeat : 1);
-  im->desc.resize((size_t)(im->nfeat ? im->nfeat : 1) * (im->dim ? im->dim : 1));
-  hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
   im->results_in_ctx = false;
+  // The arrays are sized from what the context holds NOW, never from the instance's bookkeeping: hess_fetch copies
+  // hess_count() records, so a count that disagrees (a failed run in between) means there is nothing to bring over.
+  const int held = hess_count(im->ctx, 0);
+  if (held != im->nfeat || held <= 0) {
+    if (held != im->nfeat) im->nfeat = 0;
+    im->keys.clear();
+    im->desc.clear();
+    return;
+  }
+  im->keys.resize((size_t)held);
+  im->desc.resize((size_t)held * (im->dim ? im->dim : 1));
+  hess_fetch(im->ctx, 0, im->keys.data(), im->dim ? im->desc.data() : nullptr);
 }
 // Same for the pixels of the current image.
 bool materialize_pixels(Impl* im) {
@@ -492,6 +501,8 @@ int SiftGPU::RunSIFT(int num, const SiftKeypoint* keys, int keys_have_orientatio
   const int rc = hess_run_keypoints(im->ctx, reinterpret_cast<const hess_keypoint*>(keys), num, keys_have_orientation);
   if (rc != 0) {
     std::cerr << "SiftGPU: " << hess_last_error(im->ctx) << "\n";
+    im->results_in_ctx = false;  // a failed run leaves no results
+    im->nfeat = 0;
     return 0;
   }
   collect_results(this);
@@ -512,6 +523,12 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
   InitSiftGPU();
   if (!im->ctx) return 0;
   memset(_timing, 0, sizeof(_timing));
+  // whatever the last run left is about to be replaced -- or, when this run fails at any point below, to become
+  // stale: a failed run leaves no results (SiftPyramid.h:162-163)
+  im->results_in_ctx = false;
+  im->nfeat = 0;
+  im->keys.clear();
+  im->desc.clear();
   if (_image_loaded == 0) {
     if (!load_pnm(_imgpath, im->pixels, im->w, im->h)) {
       std::cerr << "Unable to open image (this build reads PGM/PPM only): " << _imgpath << "\n";
@@ -535,6 +552,8 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
   if (rc != 0) {
     std::cerr << "SiftGPU: " << hess_last_error(im->ctx) << "\n";
     im->nfeat = 0;
+    im->keys.clear();
+    im->desc.clear();
     return 0;  // device errors -> 0 (SiftPyramid.h:162-163); oversize image is an error return here, not exit()
   }
   collect_results(this);
@@ -557,9 +576,10 @@ void SiftGPU::GetFeatureVector(SiftKeypoint* keys, float* descriptors) {  // Sif
     if (im->nfeat) hess_fetch(im->ctx, 0, reinterpret_cast<hess_keypoint*>(keys), im->dim ? descriptors : nullptr);
     return;
   }
-  if (keys && im->nfeat) memcpy(keys, im->keys.data(), (size_t)im->nfeat * sizeof(SiftKeypoint));
+  const size_t n = (size_t)(im->nfeat > 0 ? im->nfeat : 0);
+  if (keys && n && im->keys.size() >= n) memcpy(keys, im->keys.data(), n * sizeof(SiftKeypoint));
   // The reference always copies 128*n floats, over-reading its 64*n buffer in -half mode; here dim*n.
-  if (descriptors && im->dim && im->nfeat) memcpy(descriptors, im->desc.data(), (size_t)im->nfeat * im->dim * sizeof(float));
+  if (descriptors && im->dim && n && im->desc.size() >= n * im->dim) memcpy(descriptors, im->desc.data(), n * im->dim * sizeof(float));
 }
 
 void SiftGPU::SaveSIFT(const char* szFileName) {  // SiftPyramid::SaveSIFT, SiftPyramid.cpp:357-571

@@ -10,6 +10,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _fracs(node, path=""):
+    """Every fraction-of-a-peak on the line, wherever it sits."""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k in ("frac", "frac_of_measured", "frac_of_mix") and v is not None:
+                yield path + "/" + k, v
+            else:
+                yield from _fracs(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _fracs(v, f"{path}[{i}]")
+
+
 def test_bench_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--batch", "3"], capture_output=True, text=True, timeout=900)
@@ -40,6 +53,14 @@ def test_bench_json_line():
     gk = rf if rf["kernel"].startswith("gauss") else d["roofline_secondary"]
     o0 = gk["octave0_launches"]  # the Gaussian launches of octave 0, timed apart: the bandwidth-bound part of the stage
     assert o0["launches"] > 0 and 0 < o0["frac"] < 1 and o0["frac"] > gk["frac"] and 0.5 < o0["share_of_stage_bytes"] < 1
+    # no number on the line may exceed the peak it is a fraction of (round 3 published a vector-issue frac of 15.94)
+    fr = dict(_fracs(d))
+    assert len(fr) >= 8, fr
+    for where, v in fr.items():
+        assert 0.0 < v <= 1.0, (where, v)
+    # the dominant kernel of the committed kernel trace, priced with this run's bytes
+    rr = d["roofline_by_rocprof"]
+    assert rr["kernel"].startswith(("descriptor_kernel", "gauss")) and rr["avg_launch_us"] > 0 and rr["source"].startswith("profiles/")
     assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
     assert 0 < d["value_host_to_host"] and 0 < d["latency_ms_single_image"] < 100
     assert d["config"]["distinct_images_per_gpu"] == 3 and "configs[1]" in d["config"]["workload"]

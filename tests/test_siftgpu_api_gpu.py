@@ -103,3 +103,43 @@ def test_oversize_image_returns_zero_not_exit():
     s.parse(["-maxd", "4096"])
     assert s.run(np.zeros((8, 3300), np.uint8), siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
     s.close()
+
+
+def test_failed_run_leaves_no_stale_results():
+    """Good run, failing run, parameter change, run: the instance never hands out (or copies) the earlier run's
+    records after a failure (round-3 advisor finding: the context was rebuilt with 1-element arrays and hess_fetch
+    copied the stale count into them)."""
+    img = fixtures.load_rgb("640-1.jpg")
+    lum = np.ascontiguousarray(img[..., 1])
+    s = siftgpu_lib.SiftGPU([])
+    assert s.run(lum, siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    n_good = s.L.siftgpu_feature_num(s.h)
+    assert n_good > 100
+    # a run that fails inside the library ("image too small"): no features, nothing to fetch
+    assert s.run(np.zeros((2, 2), np.uint8), siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 0
+    assert s.L.siftgpu_feature_num(s.h) == 0
+    k, d = s.features()
+    assert len(k) == 0
+    # a dirty parameter rebuilds the context on the next run (drop_context -> materialize_results)
+    s.L.siftgpu_set_verbose(s.h, 2)
+    s.parse(["-maxd", "3000"])
+    assert s.run(lum, siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 1
+    assert s.L.siftgpu_feature_num(s.h) == n_good
+    k2, d2 = s.features()
+    o = OracleSession(threads=8, keep_levels=False)
+    o.run(lum[None])
+    ok, od = o.fetch(0)
+    assert k2.tobytes() == ok.tobytes() and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    # and the C ABI itself refuses the stale batch after a failed run
+    import hessgpu_amd
+    g = hessgpu_amd.HessContext(0)
+    assert g.run(lum[None])[0] == n_good
+    with pytest.raises(hessgpu_amd.HessError):
+        g.run(np.zeros((1, 2, 2), np.uint8))
+    with pytest.raises(hessgpu_amd.HessError):
+        g.count(0)
+    with pytest.raises(hessgpu_amd.HessError):
+        g.fetch(0)
+    assert g.run(lum[None])[0] == n_good
+    g.close()
+    s.close()

@@ -24,10 +24,19 @@ def main():
     g = bench["roofline"] if bench["roofline"]["kernel"].startswith("gauss") else bench["roofline_secondary"]
     traffic["algorithmic_bytes_per_launch"] = g["algorithmic_bytes_per_launch"]
     traffic["source"] = f"profiles/{tag}_* (tools/profile_round.sh {tag})"
-    # vector instructions of all Gaussian launches per image: the SQ pass runs 3 steps (--steps 2 --warmup 1) of one batch
+    # vector instructions of all Gaussian launches per image.  The number of steps the SQ pass ran is READ from the pass
+    # (every step launches the extrema scan exactly once), never assumed: round 3 divided by a hard-coded 3 after the
+    # bench had grown a 200-step leg and published 1.24e9 instead of 1.82e7.
     batch = bench["config"]["images_per_gpu_per_step"]
-    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel")))
-    traffic["valu_insts_per_image"] = round(gv / (3 * batch), 1)
+    scan = [r for k, r in rows.items() if k.startswith(("extrema_stream_kernel", "extrema_mark_kernel"))]
+    steps = sum(int(r["launches"]) for r in scan)
+    if steps <= 0:
+        raise SystemExit("make_profile_json: no extrema scan launches in counters.csv: cannot tell how many steps the pass ran")
+    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_tail_kernel")))
+    traffic["valu_insts_per_image"] = round(gv / (steps * batch), 1)
+    traffic["valu_insts_steps_in_pass"] = steps
+    if not (1.0e6 < traffic["valu_insts_per_image"] < 1.0e8):   # a 1080p pyramid is 1.5e7 - 2.5e7 vector instructions
+        raise SystemExit(f"make_profile_json: {traffic['valu_insts_per_image']} vector instructions per image is not plausible")
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
     dk = dd["kernel"].split()[0]  # the form the benched batch size uses: descriptor_kernel<false> (copier delivery) or <true> (host mirror)
@@ -51,6 +60,60 @@ def main():
     }
     json.dump(out, open(os.path.join(ROOT, "profiles", "descriptor_counters.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    top = kernel_stats_top(d, tag, bench)
+    if top:
+        json.dump(top, open(os.path.join(ROOT, "profiles", "kernel_stats_top.json"), "w"), indent=1)
+        print(json.dumps(top, indent=1))
+
+
+def short(name):
+    import re
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("hess::", "")
+    return re.sub(r"\(.*", "", name)
+
+
+def kernel_stats_top(d, tag, bench):
+    """The top row of the single-stream kernel-statistics table (rocprofv3 --kernel-trace --stats) priced against the
+    HBM roofline with the algorithmic bytes of the SAME profiled run (its bench line): what bench.py copies into
+    `roofline_by_rocprof`, so that the line and the trace name the same dominant kernel."""
+    import glob
+    f = glob.glob(os.path.join(d, "stats_ctx1", "**", "*kernel_stats.csv"), recursive=True)
+    if not f:
+        return None
+    rows = list(csv.DictReader(open(f[0])))
+    rows = [r for r in rows if "hess::" in r["Name"]]
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    r = rows[0]
+    name = short(r["Name"])
+    avg_s = float(r["AverageNs"]) * 1e-9
+    entries = [bench.get("roofline"), bench.get("roofline_secondary")]
+    e = next((x for x in entries if x and x["kernel"].split()[0].startswith(name.split("<")[0])), None)
+    if e is None:
+        return None
+    out = {
+        "kernel": name, "calls": int(r["Calls"]), "avg_launch_us": round(avg_s * 1e6, 2), "share_of_device_time": float(r["Percentage"]) / 100.0,
+        "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+        "source": f"profiles/{tag}_kernel_stats_contexts1.csv (top row) + profiles/{tag}_bench_contexts1_under_rocprof.json (bytes of the same run)",
+    }
+    if name.startswith("descriptor"):
+        b = e["algorithmic_bytes_per_launch"]
+        out.update({"algorithmic_bytes_per_launch": b, "features_per_launch": e.get("features_per_launch"),
+                    "achieved": round(b / avg_s / 1e9, 1), "frac": round(b / avg_s / 1e9 / 8000.0, 4),
+                    "hipevents_avg_launch_us_same_run": e["avg_launch_us"]})
+    else:  # one instantiation of the Gaussian kernel leads the table: price the whole family (all its rows) instead
+        fam = [x for x in rows if short(x["Name"]).startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_tail_kernel"))]
+        tot_s = sum(float(x["TotalDurationNs"]) for x in fam) * 1e-9
+        calls = sum(int(x["Calls"]) for x in fam)
+        per_step = max(1, round(e["ms_per_step"] * 1e3 / e["avg_launch_us"]))  # Gaussian launches per step (bench line)
+        bytes_step = e["algorithmic_bytes_per_launch"] * per_step
+        steps = calls / per_step                                               # steps the traced run made
+        out.update({"kernel": "gauss_kernel / gauss_pair_kernel (all instantiations; " + name + " leads the table)",
+                    "calls": calls, "avg_launch_us": round(tot_s / calls * 1e6, 2), "launches_per_step": per_step,
+                    "algorithmic_bytes_per_step": bytes_step, "achieved": round(bytes_step * steps / tot_s / 1e9, 1),
+                    "frac": round(bytes_step * steps / tot_s / 1e9 / 8000.0, 4)})
+    return out
 
 
 if __name__ == "__main__":

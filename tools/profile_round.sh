@@ -8,18 +8,18 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics, single stream (averages comparable with bench.py's hipEvent roofline leg)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ctx1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg --no-api-leg --no-configs4 --contexts 1 > $OUT/bench_ctx1.json 2> $OUT/bench_ctx1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ctx1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > $OUT/bench_ctx1.json 2> $OUT/bench_ctx1.err
 # 2. kernel statistics, default pipelined contexts (six)
 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-host-leg --no-api-leg --no-configs4 > $OUT/bench_ctxd.json 2> $OUT/bench_ctxd.err
 # 3./4. HBM traffic counters, one pass each
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_write.err
 # 5. wavefront occupancy of time (wait / issue-stall / active), one pass of 8 SQ counters
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_sq.err
 # 6. second SQ pass: LDS and memory-instruction counters
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_sq2.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_sq2.err
 # 7. effective shader clock per kernel (GRBM_GUI_ACTIVE / 8 / duration): keeps its kernel trace for the durations
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_clk -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_clk.err
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_clk -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_clk.err
 python3 $R/tools/pmc_counters.py $OUT/pmc_sq $OUT/pmc_sq2 > $OUT/counters.csv
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.json 2> $OUT/traffic.err || true
 python3 $R/tools/profile_clock_summary.py $OUT > $OUT/clock.csv 2> $OUT/clock.err || true
