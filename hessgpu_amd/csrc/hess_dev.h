@@ -165,6 +165,23 @@ struct GaussJob {
 // tap counts is not instantiated: launch them separately then.
 bool launch_gauss_pair(hipStream_t st, const GaussJob& a, const GaussJob& b, int batch);
 
+// Levels 1..nlevels (= level_ds) of one octave in one launch (gauss_chain_kernel, k_gauss.hip), and level 0 of the
+// next octave: the part of an octave the next one waits for.  The octave's top level, det-H and gradient planes follow
+// off the critical path: launch_gauss_multi, launch_hessian_level.
+struct ChainJob {
+  const float* src0;
+  float* dst[4];
+  Taps taps[4];
+  int nlevels, wa, h;
+  float* decim_dst;
+  int decim_w, decim_h;
+};
+bool launch_gauss_chain(hipStream_t st, const ChainJob& j, int batch);
+bool gauss_chain_available(const Taps* taps /* [0..level_ds] */, int level_ds);
+// Several level launches (same tap count, each with det-H and gradient of its source level) in one grid; false: not
+// instantiated for these jobs.
+bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch);
+
 // Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
                     long long img_stride, int ds, float* dst, int w, int h, int batch);
@@ -185,9 +202,11 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
                     float* got, const float* norms /* host: sigma^4 per level */, int batch,
                     int level_first, int level_last);
 // det-H of level `level` of every octave, one launch (no gradient plane); also clears `zero_bytes` (a multiple of 16)
-// at `zero` if given: the buffers the detection stages expect zeroed
+// at `zero` if given: the buffers the detection stages expect zeroed; and, for octaves >= low_first (the ones produced
+// by launch_gauss_chain), det-H + gradient/theta of levels 0 .. low_nlv-1 from HBM (norms: sigma^4 per level, host)
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch, void* zero = nullptr, size_t zero_bytes = 0);
+                          int batch, void* zero = nullptr, size_t zero_bytes = 0, int low_first = -1, int low_nlv = 0,
+                          float* got = nullptr, const float* norms = nullptr);
 
 // Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

@@ -70,6 +70,22 @@ __device__ __forceinline__ float dm_atan2f(float y, float x) {
   return r;
 }
 
+// ComputeHessian_Kernel for one pixel (ProgramCU.cu:536-559) from its 3x3 neighbourhood v<row><col> of the Gaussian
+// level: det-Hessian * sigma^4 and (|gradient| / 2, theta).  The one scalar statement of these lines in the product
+// (k_detect.hip's det-H kernels and the level-chain kernel use it; the tile kernel's fused stage is its two-wide form).
+__device__ __forceinline__ float dm_deth(float v11, float v12, float v13, float v21, float v22, float v23, float v31,
+                                         float v32, float v33, float norm) {
+  const float Lxx = fmaf(-2.0f, v22, v21) + v23;      // ProgramCU.cu:536
+  const float Lyy = fmaf(-2.0f, v22, v12) + v32;      // :537
+  const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;  // :538
+  return fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;         // :553
+}
+__device__ __forceinline__ float2 dm_grad_theta(float v12, float v21, float v23, float v32) {
+  const float dx = v23 - v21, dy = v32 - v12;         // :556-557
+  const float gradient = 0.5f * sqrtf(fmaf(dx, dx, dy * dy));
+  return make_float2(gradient, (gradient == 0.0f) ? 0.0f : dm_atan2f(dy, dx));
+}
+
 // Two-wide forms of dm_atan01 / dm_atan2f: the same operations per component (IEEE division, fused
 // multiply-adds in the same order) and branch-free: for (0,0) the quotient is 0/1 = 0 and every later
 // step leaves 0, as the early return of the scalar form does.  The 2-vectors compile to packed FP32

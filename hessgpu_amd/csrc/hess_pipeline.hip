@@ -192,6 +192,7 @@ struct hess_ctx {
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
+  int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
   bool no_host_upload = false;     // HESS_NO_SIDE_UPLOAD: pinned input is uploaded by a copy on the context's stream (A/B switch)
   int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
   Copier cp;
@@ -690,10 +691,46 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // octave o): the top level of an octave and level 1 of the next are due together and independent, so they share a
   // launch (launch_gauss_pair) -- one launch fewer per octave in the dependent chain.
   const bool pair_levels = fused_decim && s.level_ds < s.level_max && s.level_max >= 2 && !c->no_pair;
+  // Octaves from chain_from on get levels 1..level_ds -- what the next octave waits for -- from ONE launch each
+  // (gauss_chain_kernel: 32x32 tiles computed in LDS on a shrinking halo): below 960x540 a level launch is a few dozen
+  // workgroups that mostly wait, and the fifteen of them for octaves 2-6 of a 1080p image were half of its pyramid's
+  // time.  The top levels (nobody's input) follow in one launch for all octaves, det-H / gradient of the chained
+  // octaves' levels 0..level_ds-1 with the top levels' det-H.  A single image (or two) also takes octave 1 that way.
+  // Needs the default schedule's tap counts (HESS_CHAIN_FROM=n overrides; 99: never).
+  int chain_from = g.noct;
+  if (fused_decim && s.level_max == s.level_ds + 1 && gauss_chain_available(s.taps, s.level_ds)) {
+    chain_from = c->chain_from > 0 ? c->chain_from : (batch <= 2 ? 1 : 2);
+    if (chain_from > g.noct) chain_from = g.noct;
+  }
+  const bool chained = chain_from < g.noct;
+  GaussJob top_jobs[kMaxOct];  // the top levels of the octaves that do not ride with the next octave's level 1
+  int ntop = 0;
+  double top_bytes = 0.0, top_bytes_oct0 = 0.0;
   int deferred_o = -1;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
-    // image b of level l lives at plane_ptr(.., o, l) + b*plane: a batch is contiguous per level
+    if (o >= chain_from && o >= 1) {  // (its level 0 is the decimated level_ds of octave o-1, written by that launch)
+      ChainJob cj;
+      double bytes = 0.0;
+      cj.src0 = plane_ptr(gauss, o, 0);
+      for (int l = 0; l <= s.level_ds; l++) {
+        cj.dst[l] = plane_ptr(gauss, o, l);
+        cj.taps[l] = s.taps[l];
+        // (the bytes of the fused planes are booked here although hessian_low_levels writes them: per step the sums agree)
+        if (l >= 1) bytes += level_bytes(o, l);
+      }
+      cj.nlevels = s.level_ds; cj.wa = og.wa; cj.h = og.h;
+      const bool decim = o + 1 < g.noct;
+      cj.decim_dst = decim ? plane_ptr(gauss, o + 1, 0) : nullptr;
+      cj.decim_w = decim ? g.o[o + 1].wa : 0; cj.decim_h = decim ? g.o[o + 1].h : 0;
+      {
+        ProfScope ps(c, HESS_K_GAUSS, bytes);
+        if (!launch_gauss_chain(st, cj, batch)) { set_err(c, "level-chain launch refused"); return HESS_ERR_DEVICE; }
+      }
+      top_jobs[ntop++] = level_job(o, s.level_max);
+      top_bytes += level_bytes(o, s.level_max);
+      continue;
+    }
     if (o == 0) {
       if (c->has_taps0) {
         ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (direct_u8 ? 5.0 : 8.0), HESS_K_GAUSS_OCT0);
@@ -718,6 +755,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         deferred_o = -1;
         continue;
       }
+      if (l == s.level_max && chained && o + 1 >= chain_from) {  // with the chained octaves' top levels, after the chain
+        top_jobs[ntop++] = level_job(o, l);
+        top_bytes += level_bytes(o, l);
+        if (o == 0) top_bytes_oct0 = level_bytes(o, l);
+        continue;
+      }
       if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
       ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l), o == 0 ? HESS_K_GAUSS_OCT0 : -1);
       launch_level(level_job(o, l));
@@ -726,6 +769,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   if (deferred_o >= 0) {  // (cannot happen: the last octave never defers)
     ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max));
     launch_level(level_job(deferred_o, s.level_max));
+  }
+  if (ntop) {  // the top levels left over by the chain, one launch
+    (void)top_bytes_oct0;
+    ProfScope ps(c, HESS_K_GAUSS, top_bytes);
+    if (!launch_gauss_multi(st, top_jobs, ntop, batch))
+      for (int k = 0; k < ntop; k++) launch_level(top_jobs[k]);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
@@ -738,8 +787,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       for (int o = 0; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
     } else {
       // this launch also clears the buffers of the detection stages (no fill launch of its own in the chain)
+      // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves: hessian_low_levels)
       launch_hessian_level(st, g, gauss, deth, s.level_max, s.norm[s.level_max], batch, user_mode ? nullptr : c->zeroed.p,
-                           c->zeroed_used);
+                           c->zeroed_used, chain_from, chained ? s.level_ds : 0, got, s.norm);
       c->zero_filled = !user_mode;
     }
   }
@@ -1456,6 +1506,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* m = getenv("HESS_MIRROR_MAX_BATCH")) c->mirror_max_batch = atoi(m);
   if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
   c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
+  if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
   return c;

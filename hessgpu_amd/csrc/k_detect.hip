@@ -51,55 +51,52 @@ __device__ __forceinline__ float lane_next(float v) {  // lane i <- lane i+1 (la
 
 // 4 pixels per thread, 16-byte loads/stores.  Neighbour addressing follows the reference's 1-D
 // linear texture: index +-1 wraps across row ends, anything outside [0, wa*h) reads 0.
-__global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
-  const int groups_per_row = a.wa >> 2;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= groups_per_row * a.h) return;
+// One plane (src = the Gaussian level, dh = its det-H plane, gt = its gradient plane or null); gid = this thread's
+// 4-pixel group of the plane.
+__device__ __forceinline__ void hessian_rows_body(const float* src, float* dh, float2* gt, int wa, int h, float norm,
+                                                  int gid) {
+  const int groups_per_row = wa >> 2;
+  const int nthreads = groups_per_row * h;
+  if (gid >= nthreads) return;
   // row = gid / groups_per_row without an integer division: float estimate, then one exact correction step
-  int row = (int)(((float)gid + 0.5f) * a.inv_groups);
+  int row = (int)(((float)gid + 0.5f) * (1.0f / (float)groups_per_row));
   int rem = gid - row * groups_per_row;
   if (rem < 0) { row--; rem += groups_per_row; }
   else if (rem >= groups_per_row) { row++; rem -= groups_per_row; }
   const int x = rem << 2;
-  const int z = blockIdx.y;  // l * batch + b
-  const int l = a.level_first + z / a.batch, b = z % a.batch;
-  const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
-  const float* src = a.gauss + poff;
-  const int n = a.plane;
-  const int idx = row * a.wa + x;
+  const int n = wa * h;
+  const int idx = row * wa + x;
 
   // Rows idx-wa, idx, idx+wa as 16-byte loads.  The +-1 neighbours are, in the reference's 1-D
   // addressing, simply the adjacent thread's outer elements (also across a row end), so they come
-  // from the neighbouring lanes; only the first/last lane of a wavefront (or of the grid) loads them.
+  // from the neighbouring lanes; only the first/last lane of a wavefront (or of the plane) loads them.
   float U[6], M[6], D[6];
   {
     const float4 m = *reinterpret_cast<const float4*>(src + idx);
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int iu = row >= 1 ? idx - a.wa : idx, id = row + 1 < a.h ? idx + a.wa : idx;
+    const int iu = row >= 1 ? idx - wa : idx, id = row + 1 < h ? idx + wa : idx;
     const float4 uq = *reinterpret_cast<const float4*>(src + iu);
     const float4 dq = *reinterpret_cast<const float4*>(src + id);
     if (row >= 1) u = uq;
-    if (row + 1 < a.h) d = dq;
+    if (row + 1 < h) d = dq;
     M[1] = m.x; M[2] = m.y; M[3] = m.z; M[4] = m.w;
     U[1] = u.x; U[2] = u.y; U[3] = u.z; U[4] = u.w;
     D[1] = d.x; D[2] = d.y; D[3] = d.z; D[4] = d.w;
   }
   {
     const int lane = threadIdx.x & 63;
-    const int nthreads = groups_per_row * a.h;
     const float ul = lane_prev(U[4]), ml = lane_prev(M[4]), dl = lane_prev(D[4]);
     const float ur = lane_next(U[1]), mr = lane_next(M[1]), dr = lane_next(D[1]);
     U[0] = ul; M[0] = ml; D[0] = dl;
     U[5] = ur; M[5] = mr; D[5] = dr;
+    // (gid & 63 == lane here: the callers hand consecutive gids to consecutive lanes of whole wavefronts)
     if (lane == 0) {
-      U[0] = tex1(src, n, idx - a.wa - 1); M[0] = tex1(src, n, idx - 1); D[0] = tex1(src, n, idx + a.wa - 1);
+      U[0] = tex1(src, n, idx - wa - 1); M[0] = tex1(src, n, idx - 1); D[0] = tex1(src, n, idx + wa - 1);
     }
     if (lane == 63 || gid == nthreads - 1) {
-      U[5] = tex1(src, n, idx - a.wa + 4); M[5] = tex1(src, n, idx + 4); D[5] = tex1(src, n, idx + a.wa + 4);
+      U[5] = tex1(src, n, idx - wa + 4); M[5] = tex1(src, n, idx + 4); D[5] = tex1(src, n, idx + wa + 4);
     }
   }
-  const float norm = a.norm[l];
-  const bool want_got = (l >= 1 && l <= a.dog);
   float hv[4];
   float2 gv[4];
 #pragma unroll
@@ -107,23 +104,24 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
     const float v11 = U[j], v12 = U[j + 1], v13 = U[j + 2];
     const float v21 = M[j], v22 = M[j + 1], v23 = M[j + 2];
     const float v31 = D[j], v32 = D[j + 1], v33 = D[j + 2];
-    const float Lxx = fmaf(-2.0f, v22, v21) + v23;           // ProgramCU.cu:536
-    const float Lyy = fmaf(-2.0f, v22, v12) + v32;           // :537
-    const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;       // :538
-    hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;             // :553
-    if (want_got) {
-      const float dx = v23 - v21, dy = v32 - v12;            // :556-557
-      const float gradient = 0.5f * sqrtf(fmaf(dx, dx, dy * dy));
-      gv[j].x = gradient;
-      gv[j].y = (gradient == 0.0f) ? 0.0f : dm_atan2f(dy, dx);
-    }
+    hv[j] = dm_deth(v11, v12, v13, v21, v22, v23, v31, v32, v33, norm);  // ProgramCU.cu:536-553
+    if (gt) gv[j] = dm_grad_theta(v12, v21, v23, v32);                   // :556-559
   }
-  *reinterpret_cast<float4*>(a.deth + poff + idx) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-  if (want_got) {
-    float2* g = a.got + a.got_off + ((long long)(l - 1) * a.B + b) * a.plane + idx;
+  *reinterpret_cast<float4*>(dh + idx) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+  if (gt) {
+    float2* g = gt + idx;
     *reinterpret_cast<float4*>(g) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
     *reinterpret_cast<float4*>(g + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
   }
+}
+
+__global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
+  const int z = blockIdx.y;  // l * batch + b
+  const int l = a.level_first + z / a.batch, b = z % a.batch;
+  const long long poff = a.lvl_off + ((long long)l * a.B + b) * a.plane;
+  const bool want_got = (l >= 1 && l <= a.dog);
+  hessian_rows_body(a.gauss + poff, a.deth + poff, want_got ? a.got + a.got_off + ((long long)(l - 1) * a.B + b) * a.plane : nullptr,
+                    a.wa, a.h, a.norm[l], blockIdx.x * 256 + threadIdx.x);
 }
 
 // det-Hessian only (levels without a gradient plane: the top level of an octave), 4 px x 4 rows per
@@ -133,8 +131,31 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
 // adjacent lanes, and from explicit 1-D-indexed loads at row ends and wavefront edges.
 // det-H of one level of every octave in a single launch (the octaves' top levels: nobody's source level, so no
 // Gaussian launch computes it on the side).  1 thread = 4 px x 4 rows; neighbour columns from the adjacent lanes.
+struct LevelNorms { float v[kMaxLev]; };
+
+// det-H (+ gradient/theta) of levels 0 .. nlv-1 of octaves >= first_oct from HBM: the levels the level-chain launches
+// (gauss_chain_kernel, k_gauss.hip) produce without their det-H / gradient planes.  blk -> (octave, level, 256 groups).
+__device__ __forceinline__ void hessian_low_levels(const Geom& g, const float* gauss, float* deth, float2* got,
+                                                   const LevelNorms& nm, int first_oct, int nlv, int blk, int b) {
+  int o = first_oct, nb = 0;
+  for (; o < g.noct; o++) {
+    nb = ((g.o[o].wa >> 2) * g.o[o].h + 255) >> 8;
+    if (blk < nb * nlv) break;
+    blk -= nb * nlv;
+  }
+  if (o >= g.noct) return;
+  const int lvl = blk / nb, pb = blk - lvl * nb;
+  const int n = g.o[o].plane;
+  const long long poff = g.o[o].lvl_off + ((long long)lvl * g.B + b) * n;
+  float2* gt = (lvl >= 1 && lvl <= g.dog) ? got + g.o[o].got_off + ((long long)(lvl - 1) * g.B + b) * n : nullptr;
+  hessian_rows_body(gauss + poff, deth + poff, gt, g.o[o].wa, g.o[o].h, nm.v[lvl], pb * 256 + (int)threadIdx.x);
+}
+
+// main_blocks: the workgroups of the top-level part (all octaves); the workgroups after them do levels 0 .. low_nlv-1 of
+// octaves >= low_first (hessian_low_levels).
 __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm,
-                                                            uint4* zero, long long zero_n) {
+                                                            uint4* zero, long long zero_n, int main_blocks, int low_first,
+                                                            int low_nlv, float2* got, LevelNorms nm) {
   // On the side: clear what the detection stages expect zeroed (overflow words, row counts, top-K histogram, extrema
   // masks: one allocation, hess_pipeline.hip) -- a grid-stride fill by this launch's threads instead of a fill
   // launch of its own in the dependent chain.
@@ -142,6 +163,10 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float*
     const long long nthr = (long long)gridDim.x * gridDim.y * 256;
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_n; i += nthr)
       zero[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if ((int)blockIdx.x >= main_blocks) {  // (workgroup-uniform)
+    hessian_low_levels(g, gauss, deth, got, nm, low_first, low_nlv, (int)blockIdx.x - main_blocks, (int)blockIdx.y);
+    return;
   }
   int blk = blockIdx.x, o = 0;  // block -> octave: octaves back to back, whole blocks each (uniform scalar walk)
   for (; o < g.noct - 1; o++) {
@@ -197,10 +222,7 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float*
       const float v11 = R[k - 1][j], v12 = R[k - 1][j + 1], v13 = R[k - 1][j + 2];
       const float v21 = R[k][j], v22 = R[k][j + 1], v23 = R[k][j + 2];
       const float v31 = R[k + 1][j], v32 = R[k + 1][j + 1], v33 = R[k + 1][j + 2];
-      const float Lxx = fmaf(-2.0f, v22, v21) + v23;           // ProgramCU.cu:536
-      const float Lyy = fmaf(-2.0f, v22, v12) + v32;           // :537
-      const float Lxy = (v13 - v11 + v31 - v33) * 0.25f;       // :538
-      hv[j] = fmaf(Lxx, Lyy, -(Lxy * Lxy)) * norm;             // :553
+      hv[j] = dm_deth(v11, v12, v13, v21, v22, v23, v31, v32, v33, norm);  // ProgramCU.cu:536-553
     }
     store_stream_f4(deth + poff + row * wa + x, hv[0], hv[1], hv[2], hv[3]);
   }
@@ -1094,11 +1116,17 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 }
 
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch, void* zero, size_t zero_bytes) {
-  int blocks = 0;
+                          int batch, void* zero, size_t zero_bytes, int low_first, int low_nlv, float* got,
+                          const float* norms) {
+  if (low_first < 0 || low_first > g.noct || low_nlv <= 0) { low_first = g.noct; low_nlv = 0; }
+  int blocks = 0, low_blocks = 0;
   for (int o = 0; o < g.noct; o++) blocks += ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
-  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm,
-                     reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16));
+  for (int o = low_first; o < g.noct; o++) low_blocks += low_nlv * (((g.o[o].wa >> 2) * g.o[o].h + 255) >> 8);
+  LevelNorms nm;
+  for (int l = 0; l < kMaxLev; l++) nm.v[l] = (norms && l < g.dog + 2) ? norms[l] : 0.0f;
+  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks + low_blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm,
+                     reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16), blocks, low_first, low_nlv,
+                     reinterpret_cast<float2*>(got), nm);
 }
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,

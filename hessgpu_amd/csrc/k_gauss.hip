@@ -5,33 +5,22 @@
 // (GLTexImage.cpp:802-916).  By bytes HBM-bound (4 B read + 4 B written per pixel and level, + 4/12 B for
 // the fused planes); measured, vector-ALU issue is the contended resource.
 //
-// gauss_march_kernel (the shipped form): a workgroup (256 threads = 4 wavefronts) owns a strip of 64 columns and
-// marches down a run of its rows, 32 source rows per step; every source row is staged and filtered horizontally ONCE
-// (the 64x32 tile form below re-filters its 2R halo rows per tile: 1.31x (R = 5) to 1.63x (R = 10) the needed work):
-//   stage    source rows [a-2, a+32) x cols [x0-R4, x0+64+R4) -> LDS `raw`, 16-byte global loads issued one step ahead
-//            (they are in flight while the previous step computes), borders replicated as the reference clamps its
-//            fetch index; the per-thread load slots keep their column/LDS addresses from step to step;
-//   stage 1b (HESS) det-Hessian*sigma^4 and (gradient/2, theta) of the SOURCE level for rows [a-1, a+31) from the
-//            staged window, in the same launch (ComputeHessian_Kernel, ProgramCU.cu:523-595): the level is not re-read;
-//   H pass   one 8-output task per thread (32 rows x 8 groups) from a register window (ds_read_b128), results into a
-//            ring of 32 + 2R rows kept twice (slot t and t + C) so that the vertical pass reads 4 + 2R consecutive rows
-//            from a per-step base with immediate offsets, whatever the ring position;
-//   V pass   output rows [a-R, a+32-R): a thread produces 4 rows x 2 columns (ds_read_b64, 8-byte coalesced stores,
-//            512 contiguous bytes per wavefront); the launch that produces the down-sampling level also stores its even
-//            rows and columns as level 0 of the next octave.
-// Work is cut into equal runs of rows over the (image, strip, row) order, one run per workgroup and about as many
-// workgroups as the chip holds at once (a run may end one strip and begin the next): no tail of half-empty rounds.
-// gauss_kernel: the 64x32 tile form of rounds 1-2 (build with -DHESS_GAUSS_TILES=1 for A/B runs):
+// gauss_kernel (the shipped form): a workgroup (256 threads = 4 wavefronts) produces one 64x32 tile of one level:
 //   stage 1  source rows [y0-R, y0+32+R) x cols [x0-R4, x0+64+R4) -> LDS `s`, 16-byte global loads,
 //            borders replicated exactly as the reference clamps its fetch index;
-//   stage 1b (HESS) as above;
+//   stage 1b (HESS) det-Hessian*sigma^4 and (gradient/2, theta) of the SOURCE level for the tile from the staged
+//            window, in the same launch (ComputeHessian_Kernel, ProgramCU.cu:523-595): the level is not re-read;
 //   stage 2  horizontal pass LDS->LDS: a thread produces 8 adjacent outputs from a register window
 //            (ds_read_b128, row stride = 4 mod 8 dwords: conflict-free);
 //   stage 3  vertical pass LDS->HBM: a thread produces 4 rows x 2 columns (ds_read_b64, 8-byte
-//            coalesced stores, 512 contiguous bytes per wavefront).
+//            coalesced stores, 512 contiguous bytes per wavefront); the launch that produces the down-sampling level
+//            also stores its even rows and columns as level 0 of the next octave.
+// The column-strip march of round 3 (every source row filtered horizontally once; bit-identical, 21 % fewer vector
+// instructions, 50 % slower) is kept as a patch against this file: profiles/r03_experiments/gauss_march.diff.
 // Per output the taps are accumulated in the reference's order: v = 0; v = fma(x_i, k_i, v), i=0..FW-1.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "hess_dev.h"
 #include "hess_devmath.h"
@@ -41,40 +30,6 @@ namespace hess {
 namespace {
 
 constexpr int TW = 64, TH = 32, NT = 256;
-#ifndef HESS_GAUSS_TILES
-#define HESS_GAUSS_TILES 1      // 0: the column-strip march instead of the 64x32 tile kernel (A/B builds; measured slower)
-#endif
-// Diagnostic build (-DHESS_GAUSS_STAMPS=1, tools/gauss_stamps.py): every wavefront adds the shader cycles it spends in
-// each phase to a device-side table (s_memtime stamps; phase boundaries force the waits the real kernel leaves to the
-// hardware, so the build is for SHARES, not for its run time).  Never in the product build.
-#ifndef HESS_GAUSS_STAMPS
-#define HESS_GAUSS_STAMPS 0
-#endif
-#if HESS_GAUSS_STAMPS
-constexpr int kStampWaves = 1 << 16;
-__device__ unsigned long long g_gstamp[kStampWaves * 8];  // per wavefront slot (private: no atomics), 7 phases + a visit count
-__device__ __forceinline__ unsigned long long gstamp_now() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define GSTAMP_BEGIN unsigned long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 1}; unsigned long long st_prev_ = gstamp_now();
-#define GSTAMP(k) do { const unsigned long long t_ = gstamp_now(); st_acc_[k] += t_ - st_prev_; st_prev_ = gstamp_now(); } while (0)
-#define GSTAMP_END do { if ((threadIdx.x & 63) == 0) { unsigned long long* p_ = g_gstamp + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kStampWaves - 1)) * 8; \
-    for (int q_ = 0; q_ < 8; q_++) p_[q_] += st_acc_[q_]; } } while (0)
-#define GSTAMP_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define GSTAMP_BEGIN
-#define GSTAMP(k)
-#define GSTAMP_END
-#define GSTAMP_VMWAIT()
-#endif
-#ifndef HESS_GAUSS_WG_PER_CU
-#define HESS_GAUSS_WG_PER_CU 3  // march form: workgroups per CU the run length is sized for
-#endif
-
 struct GaussArgs {
   const float* src;
   const uint8_t* src_u8;
@@ -91,7 +46,6 @@ struct GaussArgs {
   // ProgramCU.cu:312-326: dst(x, y) = src(min(2x, w-1), 2y)); null unless this launch produces the down-sampling level
   float* decim_dst;  // [batch][dh][dw]
   int dw, dh;
-  int rows_per_wg, nwg;  // march form: rows of the (image, strip, row) order per workgroup, workgroups with work
   Taps taps;
 };
 
@@ -130,7 +84,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
   const int x0 = txi * TW, y0 = tyi * TH;
   const long long img = tz;
 
-  GSTAMP_BEGIN
   // ---- stage 1: global -> LDS, replicate borders (ProgramCU.cu:138, :201) ----
   // All of a thread's loads are issued before its first LDS store, so their HBM latencies overlap.
   constexpr int NIT = (ROWS * NG + NT - 1) / NT;
@@ -156,9 +109,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       stage[it] = *reinterpret_cast<const float4*>(row + xs);
     }
   }
-  GSTAMP(0);  // index arithmetic + load issue
-  GSTAMP_VMWAIT();
-  GSTAMP(1);  // waiting for the source loads
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     int g = it * NT + tid;
@@ -179,7 +129,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     }
   }
   __syncthreads();
-  GSTAMP(2);  // LDS stores + barrier
 
   // ---- stage 1b (HESS): det-Hessian*sigma^4 and (gradient, theta) of the SOURCE level for this tile,
   // straight from the staged source window: the level is never re-read from HBM for it
@@ -262,7 +211,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     }
   }
 
-  GSTAMP(3);  // fused det-H / gradient stage (compute + store issue)
   // ---- stage 2: horizontal pass, LDS -> LDS in place ----
   // Every thread first computes its (at most two) 8-output tasks from the source window into registers;
   // after a barrier (all windows read) the results overwrite columns 0..63 of their row.  One LDS array
@@ -303,7 +251,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     }
   }
   __syncthreads();
-  GSTAMP(4);  // horizontal pass + its two barriers
 
   // ---- stage 3: vertical pass, LDS -> HBM ----
   {
@@ -347,10 +294,6 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       }
     }
   }
-  GSTAMP(5);  // vertical pass (compute + store issue)
-  GSTAMP_VMWAIT();
-  GSTAMP(6);  // stores draining
-  GSTAMP_END;
 }
 
 template <int R, bool U8, bool HESS>
@@ -372,274 +315,243 @@ __global__ __launch_bounds__(NT) void gauss_pair_kernel(GaussArgs a, GaussArgs b
 }
 
 // ------------------------------------------------------------------------------------------------
-// Column-strip march (see the file header).  RS source rows per step; ring of C = RS + R2 horizontally filtered rows
-// (R2 = 2R rounded up to a multiple of 4), every row stored at slot t and t + C.
-constexpr int RS = 32;
+// Level chain: levels 1 .. level_ds of one octave in ONE launch -- the levels the NEXT octave waits for.
+//
+// The pyramid's dependency graph is a chain: level l needs level l-1, and level 0 of octave o+1 is the decimated level
+// level_ds (3) of octave o.  Below 960x540 a level launch is a few dozen workgroups that spend their 4 - 6 us mostly on
+// latency, and the fifteen launches of octaves 2 - 6 of a 1080p image took 100 of the 190 us of its pyramid (42 % of the
+// Gaussian stage's time for 21 % of its bytes at batches of 8).  What the next octave needs of this one is only level
+// level_ds; the top level, the det-Hessian and the gradient planes are nobody's input inside the pyramid.  So:
+//   gauss_chain_kernel  one workgroup produces a 32x32 tile of levels 1, 2 and 3 from level 0, in LDS, trading the
+//                       dependent launches for redundant arithmetic on a shrinking halo (level l is computed on the
+//                       tile grown by the radii of the levels still to come: 14, 8, 0 pixels), and stores level 3's
+//                       even rows / columns as level 0 of the next octave (DownsampleKernel, ProgramCU.cu:312-326): one
+//                       launch per octave on the critical path;
+//   off the critical path, after the last octave: level 4 of all octaves in one launch (gauss_multi_kernel below: the
+//                       tile kernel, which also emits det-H / gradient of its source level 3) and det-H / gradient of
+//                       levels 0 - 2 of the chained octaves from HBM (hessian_rows in k_detect.hip, same launch as the
+//                       top levels' det-H).
+// Inside the workgroup, per level: horizontal pass in place (4 outputs per task from a register window of ds_read_b128,
+// all windows read before the first result is written), vertical pass into the other LDS region (4 rows x 2 columns per
+// task, ds_read_b64), then the tile goes to HBM.  Borders as the reference clamps its fetch index (ProgramCU.cu:138,201):
+// columns outside the image hold the value of the clamped column (stage 0 / a fix-up after each level, border tiles
+// only), rows outside the image are never computed -- the vertical pass of a border tile clamps its row index instead.
+// Every value is the tap chain `v = 0; v = fma(x_i, k_i, v)` of the tile kernel on the same inputs, so the planes are
+// bit-identical to the level-by-level launches whatever the tiling.  Instantiated for the radii of the reference's
+// default schedule (11, 13, 17 taps for levels 1 - 3); other schedules keep the level-by-level launches.
+constexpr int CT = 32;     // tile side
+constexpr int CNT = 1024;  // threads per workgroup
+constexpr int CNL = 3;     // levels per chain launch (= level_ds of the default schedule)
 
-template <int R, bool U8, bool HESS>
-__global__ __launch_bounds__(NT) void gauss_march_kernel(GaussArgs a) {
-  constexpr int FW = 2 * R + 1;
-  constexpr int R4 = (R + 3) & ~3;
-  constexpr int OFF = R4 - R;
-  constexpr int SW = TW + 2 * R4;       // staged columns per row
-  constexpr int RWP = SW + 4;           // SW % 8 == 0 -> raw row pitch = 4 (mod 8) dwords
-  constexpr int RROWS = RS + 2;         // source rows a-2 .. a+RS-1: the two rows above feed the fused det-H stage
-  constexpr int NG = SW / 4;            // 16-byte groups per staged row
-  constexpr int NIT = (RROWS * NG + NT - 1) / NT;
-  constexpr int R2 = (2 * R + 3) & ~3;
-  constexpr int C = RS + R2;            // ring rows
-  constexpr int HP = TW + 4;            // ring row pitch
-  constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
-  static_assert(RS * (TW / 8) == NT, "one horizontal task per thread");
-  static_assert(2 * R <= RS, "ring geometry");
+struct ChainArgs {
+  const float* src0;     // level 0 of the octave, [batch][h][w]
+  float* dst[CNL + 1];   // levels 1..3 ([0] unused)
+  int w, h, tiles_x, tiles_y, batch;
+  float* decim_dst;      // level 0 of the next octave, [batch][dh][dw] (null: last octave)
+  int dw, dh;
+  Taps taps[CNL + 1];    // taps[l] produces level l from level l-1
+};
 
-  __shared__ __attribute__((aligned(16))) float raw[RROWS * RWP];
-  __shared__ __attribute__((aligned(16))) float ring[2 * C * HP];
+template <int R1, int R2, int R3>
+struct ChainShape {
+  static constexpr int R(int l) { return l == 1 ? R1 : l == 2 ? R2 : R3; }
+  static constexpr int R4up(int l) { return (R(l) + 3) & ~3; }
+  static constexpr int H(int l) { return l >= CNL ? 0 : H(l + 1) + R(l + 1); }  // halo of level l around the tile
+  static constexpr int max2(int a, int b) { return a > b ? a : b; }
+  // column origin of the tile inside the LDS rows: every 16-byte aligned register window of the horizontal passes
+  // starts at a column >= 0
+  static constexpr int orgx() {
+    int m = H(0);
+    for (int l = 1; l <= CNL; l++) m = max2(m, H(l) + 3 + R4up(l));
+    return (m + 3) & ~3;
+  }
+  static constexpr int ORGX = orgx();
+  static constexpr int ORGY = H(0);
+  static constexpr int ncol() {
+    int m = ORGX + CT + H(0);
+    for (int l = 1; l <= CNL; l++) m = max2(m, ((ORGX + CT + H(l) - 1) & ~3) + 4 + R4up(l));
+    return (m + 3) & ~3;
+  }
+  static constexpr int NCOL = ncol();
+  static constexpr int STRIDE = NCOL + 4;
+  static constexpr int NROW = CT + 2 * H(0);
+  static constexpr int REGION = NROW * STRIDE;  // floats per LDS region; two regions
+};
 
+template <int R1, int R2, int R3>
+__global__ __launch_bounds__(CNT) void gauss_chain_kernel(ChainArgs a) {
+  using S = ChainShape<R1, R2, R3>;
+  constexpr int ORGX = S::ORGX, ORGY = S::ORGY, STRIDE = S::STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * S::REGION];
+  float* const X = lds;
+  float* const Y = lds + S::REGION;
   const int tid = threadIdx.x;
   const int w = a.w, h = a.h;
-  // XCD-aware order of the runs: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so XCD k
-  // takes the k-th contiguous eighth of the run sequence: runs that share halo columns / boundary rows -- neighbours
-  // in the (image, strip, row) order, a few runs apart -- are served by the same 4 MiB L2 at about the same time.
-  const int per_xcd = (a.nwg + 7) >> 3;
-  const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (wid >= a.nwg) return;
-  GSTAMP_BEGIN
-  const long long total = (long long)a.batch * a.tiles_x * h;
-  long long g = (long long)wid * a.rows_per_wg;
-  const long long gend = min(total, g + (long long)a.rows_per_wg);
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int img = (int)blockIdx.x / per_img;
+  const int trem = (int)blockIdx.x - img * per_img;
+  const int tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
+  const int x0 = txi * CT, y0 = tyi * CT;
+  const long long ioff = (long long)img * w * h;
+  const int tx = tid & 31, ty = tid >> 5;  // this thread's pixel of the tile
+  const int gx = x0 + tx, gy = y0 + ty;
+  const bool px_in = gx < w && gy < h;
+  // LDS row / column of image row 0 / column 0, of the last image row / column (may lie outside the arrays)
+  const int row_lo = ORGY - y0, row_hi = ORGY + (h - 1 - y0);
+  const int col_lo = ORGX - x0, col_hi = ORGX + (w - 1 - x0);
 
-  // per-thread constants of the passes
-  const int hrow = tid >> 3, hxb = (tid & 7) * 8;  // horizontal task: source row a + hrow, outputs hxb .. hxb+7
-  const int cg = tid & 31, rg = tid >> 5;          // vertical task: columns 2cg, 2cg+1, rows 4rg .. 4rg+3 of the step
-
-  while (g < gend) {  // one piece = rows [ys, ye) of one strip of one image (a run may end a strip and begin the next)
-    const int colid = (int)(g / h);
-    const int ys = (int)(g - (long long)colid * h);
-    const int ye = (int)min((long long)h, (long long)ys + (gend - g));
-    const int img = colid / a.tiles_x;
-    const int x0 = (colid - img * a.tiles_x) * TW;
-    g += ye - ys;
-    const int nsteps = (ye - ys + 2 * R + RS - 1) / RS;
-    const bool border = (x0 - R4 < 0) || (x0 + TW + R4 > w);  // strip-uniform
-
-    // load slots of this thread: fixed LDS destination and source column, row advancing by RS per step
-    int ldst[NIT], lrow[NIT], lcol[NIT], lflag[NIT];
+  // ---- stage 0: level 0 window -> X (rows inside the image only), columns outside the image replicated ----
+  {
+    constexpr int NG = S::NCOL / 4, ROWS = S::NROW;
+    constexpr int NIT = (ROWS * NG + CNT - 1) / CNT;
+    const float* plane = a.src0 + ioff;
+    float4 v[NIT];
+    int at[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      int gi = it * NT + tid;
-      gi = gi < RROWS * NG ? gi : RROWS * NG - 1;  // surplus threads repeat the last group
-      const int r = gi / NG, gx = gi - r * NG;
-      const int x = x0 - R4 + gx * 4;
-      ldst[it] = r * RWP + gx * 4;
-      lrow[it] = r;
-      lcol[it] = x < 0 ? 0 : (x >= w ? w - 4 : x);  // w is a multiple of 4
-      lflag[it] = x < 0 ? 1 : (x >= w ? 2 : 0);     // group left / right of the image: replicate the edge pixel
+      const int g = it * CNT + tid;
+      const int r = g / NG, gq = g - r * NG;
+      const int y = y0 - ORGY + r;
+      const int x = x0 - ORGX + gq * 4;
+      const bool ok = g < ROWS * NG && y >= 0 && y < h;
+      const int xs = x < 0 ? 0 : (x >= w ? w - 4 : x);  // w is a multiple of 4
+      float4 q = *reinterpret_cast<const float4*>(plane + (long long)(ok ? y : 0) * w + xs);
+      if (x < 0) q = make_float4(q.x, q.x, q.x, q.x);
+      if (x >= w) q = make_float4(q.w, q.w, q.w, q.w);
+      v[it] = q;
+      at[it] = ok ? r * STRIDE + gq * 4 : -1;
     }
-    float4 stage[NIT];
-    uint32_t stage8[NIT];
-    auto issue_loads = [&](int a0) {  // source rows a0-2 .. a0+RS-1, clamped (ProgramCU.cu:138, :201)
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        int y = a0 - 2 + lrow[it];
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        if (U8) {
-          const uint8_t* row = a.src_u8 + (long long)img * a.src_img_stride + (long long)y * a.src_pitch;
-          stage8[it] = *reinterpret_cast<const uint32_t*>(row + lcol[it]);
-        } else {
-          const float* row = a.src + (long long)img * a.src_img_stride + (long long)y * a.src_pitch;
-          stage[it] = *reinterpret_cast<const float4*>(row + lcol[it]);
-        }
-      }
-    };
-    issue_loads(ys - R);
-    int ws = 0;  // ring slot of source row a - R2 (the top of the window the vertical pass may read)
+    for (int it = 0; it < NIT; it++)
+      if (at[it] >= 0) *reinterpret_cast<float4*>(&X[at[it]]) = v[it];
+  }
+  __syncthreads();
 
-    for (int s = 0; s < nsteps; s++) {
-      const int a0 = ys - R + s * RS;  // first new source row of this step
-      GSTAMP(0);  // loop / piece bookkeeping
-      GSTAMP_VMWAIT();
-      GSTAMP(1);  // waiting for the loads issued one step ahead
-      // ---- stage: registers -> LDS (border groups patched on the way), then the next step's loads ----
+  auto level = [&](auto ltag, float* Sg, float* Dg) {
+    constexpr int L = decltype(ltag)::value;
+    constexpr int R = S::R(L), FW = 2 * R + 1, RU = S::R4up(L);
+    constexpr int HP = S::H(L - 1), HL = S::H(L);  // halo of the source level, of this level
+    // ---- horizontal pass, in place: rows of the source window (inside the image) x aligned 4-column runs that
+    // cover this level's columns (inside the image) ----
+    constexpr int RB = ORGY - HP, NRH = CT + 2 * HP;
+    constexpr int CB = (ORGX - HL) & ~3, CE = ORGX + CT + HL, NRUN = (CE - CB + 3) / 4;
+    constexpr int NTASK = NRH * NRUN, KH = (NTASK + CNT - 1) / CNT;
+    constexpr int NV = (4 + 2 * RU) / 4, OFF = RU - R;
+    static_assert(CB - RU >= 0 && CB + 4 * NRUN + RU <= S::NCOL, "register windows stay inside the LDS rows");
+    float acc[KH][4];
+    bool live[KH];
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        float4 v;
-        if (U8) {
-          const uint32_t b = stage8[it];
-          v = make_float4(dm_u8_unit((float)(b & 0xFFu)), dm_u8_unit((float)((b >> 8) & 0xFFu)),   // p / 255.0f, GLTexImage.cpp:828
-                          dm_u8_unit((float)((b >> 16) & 0xFFu)), dm_u8_unit((float)(b >> 24)));
-        } else {
-          v = stage[it];
-        }
-        if (border) {
-          const float e = lflag[it] == 1 ? v.x : v.w;
-          if (lflag[it]) v = make_float4(e, e, e, e);
-        }
-        *reinterpret_cast<float4*>(&raw[ldst[it]]) = v;
-      }
-      if (s + 1 < nsteps) issue_loads(a0 + RS);  // in flight while this step computes
-      __syncthreads();
-      GSTAMP(2);  // LDS stores, next loads issued, barrier
-
-      // ---- stage 1b (HESS): det-Hessian*sigma^4 and (gradient, theta) of source rows [a0-1, a0+RS-1) from the staged
-      // window (ComputeHessian_Kernel, ProgramCU.cu:523-595): raw row j holds source row a0-2+j.  A thread does 4
-      // adjacent pixels in each of two rows 16 apart (store shapes: see gauss_kernel below). ----
-      if (HESS) {
-        const int hx = (tid & 15) * 4;
-        const int gx = x0 + hx;
-        const bool want_got = a.got_src != nullptr;  // block-uniform
-        const float* plane = a.src + (long long)img * a.src_img_stride;
-        const int n = w * h;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          const int hr = (tid >> 4) + 16 * half;
-          const int gy = a0 - 1 + hr;
-          if (gy >= ys && gy < ye && gx < w) {
-            float U[6], M[6], D[6];  // columns gx-1 .. gx+4 of rows gy-1, gy, gy+1
-            {
-              const float* base = &raw[hr * RWP + hx + R4];
-#pragma unroll
-              for (int rr = 0; rr < 3; rr++) {
-                float* dst = rr == 0 ? U : (rr == 1 ? M : D);
-                const float4 v = *reinterpret_cast<const float4*>(base + rr * RWP);
-                dst[0] = base[rr * RWP - 1];
-                dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
-                dst[5] = base[rr * RWP + 4];
-              }
-            }
-            // The staged window replicates the image border; the reference addresses neighbours by 1-D
-            // index instead: rows outside the plane read 0, column -1 / w wraps to the adjacent row.
-            const int idx = gy * w + gx;
-            if (gy == 0) {
-#pragma unroll
-              for (int j = 0; j < 6; j++) U[j] = 0.0f;
-            }
-            if (gy == h - 1) {
-#pragma unroll
-              for (int j = 0; j < 6; j++) D[j] = 0.0f;
-            }
-            if (gx == 0) {
-              U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
-            }
-            if (gx + 4 == w) {  // this thread owns the row's last pixel (w is a multiple of 4)
-              const int il = idx + 3;
-              U[5] = gtex1(plane, n, il - w + 1); M[5] = gtex1(plane, n, il + 1); D[5] = gtex1(plane, n, il + w + 1);
-            }
-            float hv[4];
-            float2 gv[4];
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {  // two pixels at a time on 2-vectors, no per-pixel branches
-#define HESS_V2(A, K) ((v2f){A[(K)], A[(K) + 1]})
-              const v2f v11 = HESS_V2(U, j), v12 = HESS_V2(U, j + 1), v13 = HESS_V2(U, j + 2);
-              const v2f v21 = HESS_V2(M, j), v22 = HESS_V2(M, j + 1), v23 = HESS_V2(M, j + 2);
-              const v2f v31 = HESS_V2(D, j), v32 = HESS_V2(D, j + 1), v33 = HESS_V2(D, j + 2);
-#undef HESS_V2
-              const v2f Lxx = v2_fma(v2_splat(-2.0f), v22, v21) + v23;   // ProgramCU.cu:536
-              const v2f Lyy = v2_fma(v2_splat(-2.0f), v22, v12) + v32;   // :537
-              const v2f Lxy = (v13 - v11 + v31 - v33) * v2_splat(0.25f);  // :538
-              const v2f dh = v2_fma(Lxx, Lyy, -(Lxy * Lxy)) * v2_splat(a.norm_src);  // :553
-              hv[j] = dh.x; hv[j + 1] = dh.y;
-              if (want_got) {
-                const v2f dx = v23 - v21, dy = v32 - v12;                 // :556-557
-                const v2f gradient = v2_splat(0.5f) * __builtin_elementwise_sqrt(v2_fma(dx, dx, dy * dy));
-                const v2f th = dm_atan2f_x2(dy, dx);
-                gv[j].x = gradient.x;     gv[j].y = (gradient.x == 0.0f) ? 0.0f : th.x;
-                gv[j + 1].x = gradient.y; gv[j + 1].y = (gradient.y == 0.0f) ? 0.0f : th.y;
-              }
-            }
-            const long long o = (long long)img * w * h + idx;
-            *reinterpret_cast<float4*>(a.deth_src + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-            if (want_got) {
-              float2* gp = a.got_src + o;
-              *reinterpret_cast<float4*>(gp) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
-              *reinterpret_cast<float4*>(gp + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
-            }
-          }
-        }
-      }
-
-      GSTAMP(3);  // fused det-H / gradient stage (compute + store issue)
-      // ---- horizontal pass: source row a0 + hrow (raw row hrow + 2), 8 outputs, into the ring (both copies) ----
-      {
+    for (int k = 0; k < KH; k++) {
+      const int t = tid + k * CNT;
+      const int r = RB + t / NRUN, c0 = CB + 4 * (t % NRUN);
+      live[k] = t < NTASK && r >= row_lo && r <= row_hi && c0 + 3 >= col_lo && c0 <= col_hi;
+      if (live[k]) {
         float win[NV * 4];
 #pragma unroll
         for (int i = 0; i < NV; i++) {
-          const float4 q = *reinterpret_cast<const float4*>(&raw[(hrow + 2) * RWP + hxb + 4 * i]);
+          const float4 q = *reinterpret_cast<const float4*>(&Sg[r * STRIDE + c0 - RU + 4 * i]);
           win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
         }
-        float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+        for (int j = 0; j < 4; j++) acc[k][j] = 0.0f;
 #pragma unroll
         for (int i = 0; i < FW; i++) {
-          const float ki = a.taps.k[i];
+          const float ki = a.taps[L].k[i];
 #pragma unroll
-          for (int j = 0; j < 8; j++) acc[j] = fmaf(win[OFF + j + i], ki, acc[j]);  // ProgramCU.cu:152
+          for (int j = 0; j < 4; j++) acc[k][j] = fmaf(win[OFF + j + i], ki, acc[k][j]);  // ProgramCU.cu:152
         }
-        int t = ws + R2 + hrow;  // ring slot of source row a0 + hrow
-        t = t >= C ? t - C : t;
-        float* d = &ring[t * HP + hxb];
-        const float4 lo = make_float4(acc[0], acc[1], acc[2], acc[3]), hi = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        *reinterpret_cast<float4*>(d) = lo;
-        *reinterpret_cast<float4*>(d + 4) = hi;
-        *reinterpret_cast<float4*>(d + C * HP) = lo;
-        *reinterpret_cast<float4*>(d + C * HP + 4) = hi;
       }
-      __syncthreads();
-      GSTAMP(4);  // horizontal pass + barrier
-
-      // ---- vertical pass: output rows a0 - R + 4rg + j from ring rows (window-relative) R2 - 2R + 4rg + j + i ----
-      {
-        const int y0 = a0 - R + 4 * rg;
-        if (y0 + 3 >= ys && y0 < ye) {
-          const float* cbase = &ring[(ws + (R2 - 2 * R) + 4 * rg) * HP + cg * 2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KH; k++) {
+      if (live[k]) {
+        const int t = tid + k * CNT;
+        const int r = RB + t / NRUN, c0 = CB + 4 * (t % NRUN);
+        *reinterpret_cast<float4*>(&Sg[r * STRIDE + c0]) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+      }
+    }
+    __syncthreads();
+    // ---- vertical pass into the other region: 4 rows x 2 columns per task; the last run of rows is moved up onto
+    // the window's end (it recomputes up to three rows of the run before it: same values).  A tile whose window
+    // reaches beyond the first or last image row clamps the row index of its reads (the reference's clamped fetch). ----
+    constexpr int RB2 = ORGY - HL, NRV = CT + 2 * HL, NRR = (NRV + 3) / 4, NPAIR = 2 * NRUN;
+    constexpr int NTV = NRR * NPAIR, KV = (NTV + CNT - 1) / CNT;
+    auto vpass = [&](auto clamp_tag) {
+      constexpr bool CLAMP = decltype(clamp_tag)::value;
+#pragma unroll
+      for (int k = 0; k < KV; k++) {
+        const int t = tid + k * CNT;
+        const int rr = t / NPAIR, cp = t - rr * NPAIR;
+        const int r0 = RB2 + min(4 * rr, NRV - 4), c = CB + 2 * cp;
+        if (t < NTV && r0 + 3 >= row_lo && r0 <= row_hi && c + 1 >= col_lo && c <= col_hi) {
           float2 col[4 + 2 * R];
 #pragma unroll
-          for (int i = 0; i < 4 + 2 * R; i++) col[i] = *reinterpret_cast<const float2*>(cbase + i * HP);
-          float2 acc[4];
+          for (int i = 0; i < 4 + 2 * R; i++) {
+            int r = r0 - R + i;
+            if (CLAMP) r = min(max(r, row_lo), row_hi);
+            col[i] = *reinterpret_cast<const float2*>(&Sg[r * STRIDE + c]);
+          }
+          float2 out[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) acc[j] = make_float2(0.0f, 0.0f);
+          for (int j = 0; j < 4; j++) out[j] = make_float2(0.0f, 0.0f);
 #pragma unroll
           for (int i = 0; i < FW; i++) {
-            const float ki = a.taps.k[i];
+            const float ki = a.taps[L].k[i];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              acc[j].x = fmaf(col[j + i].x, ki, acc[j].x);  // ProgramCU.cu:226
-              acc[j].y = fmaf(col[j + i].y, ki, acc[j].y);
+              out[j].x = fmaf(col[j + i].x, ki, out[j].x);  // ProgramCU.cu:226
+              out[j].y = fmaf(col[j + i].y, ki, out[j].y);
             }
           }
-          const int x = x0 + cg * 2;
-          if (x < w) {
-            float* d = a.dst + (long long)img * w * h;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int y = y0 + j;
-              if (y >= ys && y < ye) *reinterpret_cast<float2*>(&d[(long long)y * w + x]) = acc[j];
-            }
-            if (a.decim_dst) {  // block-uniform.  x is even; the even rows and column .x are the sampled ones
-              float* dd = a.decim_dst + (long long)img * a.dw * a.dh;
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const int y = y0 + j;
-                if (!(y & 1) && y >= ys && y < ye && (y >> 1) < a.dh) {
-                  float* row = dd + (long long)(y >> 1) * a.dw;
-                  if ((x >> 1) < a.dw) row[x >> 1] = acc[j].x;  // (the next octave may be narrower than w/2: widths halve unaligned)
-                  // columns of the next octave beyond w/2 (its width is aligned up to 4) repeat the source's last column
-                  if (x == w - 2) for (int xx = w >> 1; xx < a.dw; xx++) row[xx] = acc[j].y;
-                }
-              }
-            }
-          }
+          for (int j = 0; j < 4; j++) *reinterpret_cast<float2*>(&Dg[(r0 + j) * STRIDE + c]) = out[j];
         }
       }
-      GSTAMP(5);  // vertical pass (compute + store issue)
-      ws += RS;
-      ws = ws >= C ? ws - C : ws;
+    };
+    if (y0 - HP < 0 || y0 + CT + HP > h) vpass(std::true_type{});  // (workgroup-uniform)
+    else vpass(std::false_type{});
+    __syncthreads();
+    // ---- columns of this level's window outside the image: the value of the clamped column (rows inside the image) ----
+    if (HL > 0 && (x0 - HL < 0 || x0 + CT + HL > w)) {  // (workgroup-uniform)
+      constexpr int NCW = CT + 2 * HL;
+      for (int idx = tid; idx < NRV * NCW; idx += CNT) {
+        const int rr = idx / NCW, cc = idx - rr * NCW;
+        const int r = RB2 + rr, c = ORGX - HL + cc;
+        if (r >= row_lo && r <= row_hi && (c < col_lo || c > col_hi)) Dg[r * STRIDE + c] = Dg[r * STRIDE + (c < col_lo ? col_lo : col_hi)];
+      }
+      __syncthreads();
     }
-    // (the next piece's first stage store follows this piece's last barrier in program order for every thread, and
-    // its first ring store follows its own stage barrier: no barrier needed between pieces)
-  }
-  GSTAMP_END;
+    // ---- the tile of this level -> HBM ----
+    if (px_in) {
+      const float v = Dg[(ORGY + ty) * STRIDE + ORGX + tx];
+      a.dst[L][ioff + (long long)gy * w + gx] = v;
+      if (L == CNL && a.decim_dst && !(gy & 1) && (gy >> 1) < a.dh) {  // dst(x, y) = src(min(2x, w-1), 2y)
+        float* row = a.decim_dst + (long long)img * a.dw * a.dh + (long long)(gy >> 1) * a.dw;
+        if (!(gx & 1) && (gx >> 1) < a.dw) row[gx >> 1] = v;
+        if (gx == w - 1) for (int xx = w >> 1; xx < a.dw; xx++) row[xx] = v;  // columns beyond w/2 repeat the last one
+      }
+    }
+  };
+  level(std::integral_constant<int, 1>{}, X, Y);
+  level(std::integral_constant<int, 2>{}, Y, X);
+  level(std::integral_constant<int, 3>{}, X, Y);
+}
+
+// ---- several independent level launches of the same tap count in one grid (the top levels of all octaves: their
+// sources, level 3 of every octave, are complete once the chain above has run): the tile kernel's body per job ----
+constexpr int kMultiJobs = 8;
+struct MultiArgs {
+  GaussArgs j[kMultiJobs];
+  int first_block[kMultiJobs + 1];  // job k owns workgroups [first_block[k], first_block[k+1])
+  int njobs;
+};
+template <int R>
+__global__ __launch_bounds__(NT) void gauss_multi_kernel(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R>()];
+  int k = 0;
+  for (int q = 1; q < m.njobs; q++) if ((int)blockIdx.x >= m.first_block[q]) k = q;  // (uniform scalar walk)
+  gauss_tile<R, false, true>(m.j[k], s, (int)blockIdx.x - m.first_block[k]);
 }
 
 template <int R>
@@ -647,7 +559,6 @@ void launch_r(hipStream_t st, GaussArgs a, int batch) {
   a.tiles_x = (a.w + TW - 1) / TW;
   a.tiles_y = (a.h + TH - 1) / TH;
   a.batch = batch;
-#if HESS_GAUSS_TILES
   const int ntile = a.tiles_x * a.tiles_y * batch;
   dim3 grid(((ntile + 7) / 8) * 8);
   if (a.src_u8)
@@ -656,25 +567,6 @@ void launch_r(hipStream_t st, GaussArgs a, int batch) {
     hipLaunchKernelGGL((gauss_kernel<R, false, true>), grid, dim3(NT), 0, st, a);
   else
     hipLaunchKernelGGL((gauss_kernel<R, false, false>), grid, dim3(NT), 0, st, a);
-#else
-  // Runs of rows_per_wg rows of the (image, strip, row) order, one per workgroup; about as many workgroups as the chip
-  // holds at once (256 CUs x HESS_GAUSS_WG_PER_CU), each run at least 64 rows, and (run + 2R) a multiple of the step so
-  // that whole runs waste no step slots.
-  const long long total = (long long)batch * a.tiles_x * a.h;
-  long long rows = (total + 256 * HESS_GAUSS_WG_PER_CU - 1) / (256 * HESS_GAUSS_WG_PER_CU);
-  if (rows < 64) rows = 64;
-  rows = ((rows + 2 * R + RS - 1) / RS) * RS - 2 * R;
-  if (rows < RS) rows = RS;
-  a.rows_per_wg = (int)rows;
-  a.nwg = (int)((total + rows - 1) / rows);
-  dim3 grid(((a.nwg + 7) / 8) * 8);
-  if (a.src_u8)
-    hipLaunchKernelGGL((gauss_march_kernel<R, true, false>), grid, dim3(NT), 0, st, a);
-  else if (a.deth_src)
-    hipLaunchKernelGGL((gauss_march_kernel<R, false, true>), grid, dim3(NT), 0, st, a);
-  else
-    hipLaunchKernelGGL((gauss_march_kernel<R, false, false>), grid, dim3(NT), 0, st, a);
-#endif
 }
 
 // ---- input conversion (GLTexImage.cpp:802-916): any format/type -> float luminance ----
@@ -797,20 +689,6 @@ void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long 
   }
 }
 
-#if HESS_GAUSS_STAMPS
-}  // namespace hess
-// diagnostic build only: read and clear the phase table (tools/gauss_stamps.py)
-extern "C" int hess_debug_gauss_stamps(unsigned long long* out) {  // out[8]: sums over the wavefront slots
-  static unsigned long long host[hess::kStampWaves * 8];
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(hess::g_gstamp), sizeof(host)) != hipSuccess) return -1;
-  for (int q = 0; q < 8; q++) out[q] = 0;
-  for (int w = 0; w < hess::kStampWaves; w++) for (int q = 0; q < 8; q++) out[q] += host[(size_t)w * 8 + q];
-  memset(host, 0, sizeof(host));
-  return hipMemcpyToSymbol(HIP_SYMBOL(hess::g_gstamp), host, sizeof(host)) == hipSuccess ? 0 : -1;
-}
-namespace hess {
-#endif
 
 namespace {
 GaussArgs job_args(const GaussJob& j, int batch) {
@@ -820,7 +698,6 @@ GaussArgs job_args(const GaussJob& j, int batch) {
   a.dst = j.dst; a.w = j.wa; a.h = j.h; a.taps = j.taps;
   a.deth_src = j.deth_src; a.got_src = reinterpret_cast<float2*>(j.got_src); a.norm_src = j.norm_src;
   a.tiles_x = (j.wa + TW - 1) / TW; a.tiles_y = (j.h + TH - 1) / TH; a.batch = batch;
-  a.rows_per_wg = 0; a.nwg = 0;
   return a;
 }
 template <int RA, int RB>
@@ -843,7 +720,6 @@ bool launch_pair_b(hipStream_t st, const GaussArgs& a, const GaussArgs& b, int r
 // for the tap counts around the reference's default schedule (a: 17-25 taps, b: 9-13); false = not this pair, launch
 // them one after the other.
 bool launch_gauss_pair(hipStream_t st, const GaussJob& ja, const GaussJob& jb, int batch) {
-#if HESS_GAUSS_TILES
   if (!ja.deth_src || !jb.deth_src) return false;
   const GaussArgs a = job_args(ja, batch), b = job_args(jb, batch);
   const int rb = jb.taps.fw >> 1;
@@ -855,10 +731,58 @@ bool launch_gauss_pair(hipStream_t st, const GaussJob& ja, const GaussJob& jb, i
     case 12: return launch_pair_b<12>(st, a, b, rb);
     default: return false;
   }
-#else
-  (void)st; (void)ja; (void)jb; (void)batch;
-  return false;
-#endif
+}
+
+// Levels 1..3 of one octave in one launch (+ level 0 of the next octave); false: not this schedule (launch the levels
+// one by one).
+bool gauss_chain_available(const Taps* taps, int level_ds) {
+  return level_ds == CNL && taps[1].fw == 11 && taps[2].fw == 13 && taps[3].fw == 17;
+}
+
+bool launch_gauss_chain(hipStream_t st, const ChainJob& j, int batch) {
+  if (!gauss_chain_available(j.taps, j.nlevels)) return false;
+  ChainArgs a;
+  a.src0 = j.src0;
+  for (int l = 0; l <= CNL; l++) { a.dst[l] = l ? j.dst[l] : nullptr; a.taps[l] = j.taps[l]; }
+  a.w = j.wa; a.h = j.h; a.tiles_x = (j.wa + CT - 1) / CT; a.tiles_y = (j.h + CT - 1) / CT; a.batch = batch;
+  a.decim_dst = j.decim_dst; a.dw = j.decim_w; a.dh = j.decim_h;
+  hipLaunchKernelGGL((gauss_chain_kernel<5, 6, 8>), dim3(a.tiles_x * a.tiles_y * batch), dim3(CNT), 0, st, a);
+  return true;
+}
+
+// Level launches with the same tap count and a det-H / gradient plane of their source, all in one grid.
+namespace {
+template <int R>
+void launch_multi_r(hipStream_t st, const MultiArgs& m, int blocks) {
+  hipLaunchKernelGGL((gauss_multi_kernel<R>), dim3(blocks), dim3(NT), 0, st, m);
+}
+}  // namespace
+bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch) {
+  if (njobs < 1) return true;
+  const int r = jobs[0].taps.fw >> 1;
+  if (r < 8 || r > 12) return false;
+  for (int k = 0; k < njobs; k++)
+    if (!jobs[k].deth_src || !jobs[k].got_src || (jobs[k].taps.fw >> 1) != r) return false;
+  for (int k0 = 0; k0 < njobs; k0 += kMultiJobs) {
+    MultiArgs m;
+    m.njobs = njobs - k0 < kMultiJobs ? njobs - k0 : kMultiJobs;
+    int blocks = 0;
+    for (int k = 0; k < m.njobs; k++) {
+      m.j[k] = job_args(jobs[k0 + k], batch);
+      m.first_block[k] = blocks;
+      blocks += ((m.j[k].tiles_x * m.j[k].tiles_y * batch + 7) / 8) * 8;
+    }
+    for (int k = m.njobs; k < kMultiJobs; k++) { m.j[k] = m.j[0]; m.first_block[k] = blocks; }
+    m.first_block[kMultiJobs] = blocks;
+    switch (r) {
+      case 8: launch_multi_r<8>(st, m, blocks); break;
+      case 9: launch_multi_r<9>(st, m, blocks); break;
+      case 10: launch_multi_r<10>(st, m, blocks); break;
+      case 11: launch_multi_r<11>(st, m, blocks); break;
+      default: launch_multi_r<12>(st, m, blocks); break;
+    }
+  }
+  return true;
 }
 
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
