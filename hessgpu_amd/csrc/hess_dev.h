@@ -179,8 +179,17 @@ struct ChainJob {
 bool launch_gauss_chain(hipStream_t st, const ChainJob& j, int batch);
 bool gauss_chain_available(const Taps* taps /* [0..level_ds] */, int level_ds);
 // Several level launches (same tap count, each with det-H and gradient of its source level) in one grid; false: not
-// instantiated for these jobs.
-bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch);
+// instantiated for these jobs.  low: the same launch also computes det-H + gradient/theta of levels 0 .. low_nlv-1 of
+// octaves >= low_first from HBM (the levels launch_gauss_chain produced without them).
+struct LowLevels {
+  const Geom* g;
+  const float* gauss;
+  float* deth;
+  float* got;
+  const float* norms;  // sigma^4 per level (host)
+  int first_oct, nlv;
+};
+bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch, const LowLevels* low = nullptr);
 
 // Input conversion to float luminance with 2^ds decimation (GLTexImage.cpp:802-916).
 void launch_convert(hipStream_t st, const void* src, int format, int pixtype, long long pitch,
@@ -202,11 +211,9 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
                     float* got, const float* norms /* host: sigma^4 per level */, int batch,
                     int level_first, int level_last);
 // det-H of level `level` of every octave, one launch (no gradient plane); also clears `zero_bytes` (a multiple of 16)
-// at `zero` if given: the buffers the detection stages expect zeroed; and, for octaves >= low_first (the ones produced
-// by launch_gauss_chain), det-H + gradient/theta of levels 0 .. low_nlv-1 from HBM (norms: sigma^4 per level, host)
+// at `zero` if given: the buffers the detection stages expect zeroed
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch, void* zero = nullptr, size_t zero_bytes = 0, int low_first = -1, int low_nlv = 0,
-                          float* got = nullptr, const float* norms = nullptr);
+                          int batch, void* zero = nullptr, size_t zero_bytes = 0);
 
 // Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
@@ -216,19 +223,22 @@ void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, 
 void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt,
                      int* rowoff, int* level_count, int* raw_total, int cap_raw, int* overflow,
                      int batch);
-// Extrema scan, pass 2: ordered scatter of the detections into the raw list.
-void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                            const float* deth, const uint64_t* rowmask, const int* rowoff,
-                            const int* raw_total, RawKey* raw, int cap_raw, int batch,
+// Extrema scan, pass 2: row counts -> exclusive offsets in list order (level totals, -tc level truncation:
+// GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278) and the ordered scatter
+// of the detections into the raw list.  Images of up to 8192 rows: one launch (every scatter workgroup scans the counts
+// in LDS); larger ones: row_scan_kernel first (rowoff in HBM).
+void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const LimitParams& lp, const float* gauss,
+                            const float* deth, const uint64_t* rowmask, const int* rowcnt, int* rowoff, int* level_count,
+                            int* raw_total, int* overflow, RawKey* raw, int cap_raw, int batch,
                             unsigned* hist = nullptr, int topk = 0);  // hist: top-K key histogram, counted on the way
 
 // Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
-// the lower list index, order preserved.  sel may alias nothing; when total < K the list is copied.
-// scratch: topk_scratch_bytes(cap_raw, batch) bytes of device memory (chunk counts, cut bins).
+// the lower list index, order preserved; when total < K the list is copied.  One launch (ticketed chunks with a
+// look-back over the chunk counts).  scratch: topk_scratch_bytes(cap_raw, batch, nlev) bytes of device memory that
+// arrive ZEROED (tickets, chunk words, kept entries per level).
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total,
-                 int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count,
-                 int cap_sel, int batch, void* scratch);
-size_t topk_scratch_bytes(int cap_raw, int batch);
+                 int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch);
+size_t topk_scratch_bytes(int cap_raw, int batch, int nlev);
 
 // Orientation (ComputeOrientation_Kernel, ProgramCU.cu:1221-1605): one wavefront per keypoint.
 void launch_orientation(hipStream_t st, const Geom& g, const OrientParams& op, const RawKey* list,

@@ -161,13 +161,13 @@ struct hess_ctx {
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
   DevBuf gauss, deth, got, input_f32, upsampled, stage, rowoff, level_count, raw_total, raw, sel,
-      sel_total, sel_level_count, tk_scratch, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
+      sel_total, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
   // Everything the detection stages expect zeroed lives in one allocation and is cleared by one fill per batch:
   // overflow flags, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
   DevBuf zeroed;
   size_t zeroed_used = 0;
   bool zero_filled = false;  // the running batch's det-H launch has cleared `zeroed`
-  struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist;
+  struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist, tk;  // tk: tickets, chunk words, per-level counts of the top-K launch
   // host results
   int batch = 0;          // images whose results the context holds (0 after a failed or while a pending run: hess_count /
                           // hess_fetch / hess_device_results refuse instead of handing out the run before)
@@ -512,14 +512,14 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_cnt = 256, o_hist = o_cnt + up((size_t)B * g.NR * 4);
     const size_t o_mask = o_hist + (c->use_topk ? up((size_t)B * kHistBins * 4) : 0);
-    c->zeroed_used = o_mask + up((size_t)B * g.NM * 8);
+    const size_t o_tk = o_mask + up((size_t)B * g.NM * 8);
+    c->zeroed_used = o_tk + (c->use_topk ? up(topk_scratch_bytes(cap_raw, B, g.nlev)) : 0);
     if ((rc = ensure(c, c->zeroed, c->zeroed_used))) return rc;
     char* z = (char*)c->zeroed.p;
-    c->overflow.p = z; c->rowcnt.p = z + o_cnt; c->hist.p = z + o_hist; c->rowmask.p = z + o_mask;
+    c->overflow.p = z; c->rowcnt.p = z + o_cnt; c->hist.p = z + o_hist; c->rowmask.p = z + o_mask; c->tk.p = z + o_tk;
   }
   if ((rc = ensure(c, c->rowoff, (size_t)B * g.NR * 4))) return rc;
   if ((rc = ensure(c, c->level_count, (size_t)B * g.nlev * 4))) return rc;
-  if ((rc = ensure(c, c->sel_level_count, (size_t)B * g.nlev * 4))) return rc;
   if ((rc = ensure(c, c->raw_total, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->sel_total, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->feat_total, (size_t)B * 4))) return rc;
@@ -528,7 +528,6 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
   if (c->use_topk) {
     if ((rc = ensure(c, c->sel, (size_t)B * cap_sel * sizeof(RawKey)))) return rc;
-    if ((rc = ensure(c, c->tk_scratch, topk_scratch_bytes(cap_raw, B)))) return rc;
   }
   if ((rc = ensure(c, c->recs, (size_t)B * cap_sel * sizeof(FRec)))) return rc;
   if ((rc = ensure(c, c->ocount, (size_t)B * cap_sel * 4))) return rc;
@@ -691,15 +690,19 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // octave o): the top level of an octave and level 1 of the next are due together and independent, so they share a
   // launch (launch_gauss_pair) -- one launch fewer per octave in the dependent chain.
   const bool pair_levels = fused_decim && s.level_ds < s.level_max && s.level_max >= 2 && !c->no_pair;
-  // Octaves from chain_from on get levels 1..level_ds -- what the next octave waits for -- from ONE launch each
-  // (gauss_chain_kernel: 32x32 tiles computed in LDS on a shrinking halo): below 960x540 a level launch is a few dozen
-  // workgroups that mostly wait, and the fifteen of them for octaves 2-6 of a 1080p image were half of its pyramid's
-  // time.  The top levels (nobody's input) follow in one launch for all octaves, det-H / gradient of the chained
-  // octaves' levels 0..level_ds-1 with the top levels' det-H.  A single image (or two) also takes octave 1 that way.
-  // Needs the default schedule's tap counts (HESS_CHAIN_FROM=n overrides; 99: never).
+  // A single image (or two): octaves from 1 on get levels 1..level_ds -- what the next octave waits for -- from ONE
+  // launch each (gauss_chain_kernel: 32x32 tiles computed in LDS on a shrinking halo): below 960x540 a level launch is a
+  // few dozen workgroups that mostly wait, and the eighteen of them for octaves 1-6 of a 1080p image were two thirds of
+  // its pyramid's time.  The top levels (nobody's input) follow in one launch for all octaves, together with det-H /
+  // gradient of the chained octaves' levels 0..level_ds-1.  Same box, one 1080p image, device-resident: 0.400 -> 0.334 ms.
+  // NOT for larger batches: a batch of 8 is 2 % faster on one stream with octaves >= 2 chained, but six pipelined
+  // contexts lose 2 - 4 % (15.5 - 15.6 against 16.1 - 16.2 Gpix/s, same call; 15.8 - 16.0 with octaves >= 3) -- the chain
+  // trades dependent launches for redundant arithmetic in 1024-thread workgroups that wait at barriers, which is what
+  // an idle device wants and a saturated one does not.  Needs the default schedule's tap counts.
+  // HESS_CHAIN_FROM=n forces the first chained octave (99: never).
   int chain_from = g.noct;
   if (fused_decim && s.level_max == s.level_ds + 1 && gauss_chain_available(s.taps, s.level_ds)) {
-    chain_from = c->chain_from > 0 ? c->chain_from : (batch <= 2 ? 1 : 2);
+    chain_from = c->chain_from > 0 ? c->chain_from : (batch <= 2 ? 1 : g.noct);
     if (chain_from > g.noct) chain_from = g.noct;
   }
   const bool chained = chain_from < g.noct;
@@ -773,8 +776,13 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   if (ntop) {  // the top levels left over by the chain, one launch
     (void)top_bytes_oct0;
     ProfScope ps(c, HESS_K_GAUSS, top_bytes);
-    if (!launch_gauss_multi(st, top_jobs, ntop, batch))
+    // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves, from HBM: hessian_low_levels)
+    LowLevels low{&g, gauss, deth, got, s.norm, chain_from, chained ? s.level_ds : 0};
+    if (!launch_gauss_multi(st, top_jobs, ntop, batch, &low)) {
       for (int k = 0; k < ntop; k++) launch_level(top_jobs[k]);
+      if (chained)  // (not reached with the schedules the chain is instantiated for)
+        for (int o = chain_from; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, 0, s.level_ds - 1);
+    }
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
@@ -787,9 +795,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       for (int o = 0; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
     } else {
       // this launch also clears the buffers of the detection stages (no fill launch of its own in the chain)
-      // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves: hessian_low_levels)
       launch_hessian_level(st, g, gauss, deth, s.level_max, s.norm[s.level_max], batch, user_mode ? nullptr : c->zeroed.p,
-                           c->zeroed_used, chain_from, chained ? s.level_ds : 0, got, s.norm);
+                           c->zeroed_used);
       c->zero_filled = !user_mode;
     }
   }
@@ -816,13 +823,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
-  launch_row_scan(st, g, lp, (const int*)c->rowcnt.p, (int*)c->rowoff.p, (int*)c->level_count.p,
-                  (int*)c->raw_total.p, c->cap_raw, (int*)c->overflow.p, batch);
   {
     ProfScope ps(c, HESS_K_EXTREMA, 0.0);
-    launch_extrema_scatter(st, g, dp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowoff.p,
-                           (const int*)c->raw_total.p, (RawKey*)c->raw.p, c->cap_raw, batch,
-                           c->use_topk ? (unsigned*)c->hist.p : nullptr, p.feature_count_threshold);
+    launch_extrema_scatter(st, g, dp, lp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowcnt.p,
+                           (int*)c->rowoff.p, (int*)c->level_count.p, (int*)c->raw_total.p, (int*)c->overflow.p,
+                           (RawKey*)c->raw.p, c->cap_raw, batch, c->use_topk ? (unsigned*)c->hist.p : nullptr,
+                           p.feature_count_threshold);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[3], st));
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
@@ -832,8 +838,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   if (c->use_topk) {
     ProfScope ps(c, HESS_K_TOPK, 0.0);
     launch_topk(st, g, p.feature_count_threshold, (const RawKey*)c->raw.p, (const int*)c->raw_total.p, c->cap_raw,
-                (unsigned*)c->hist.p, (RawKey*)c->sel.p, (int*)c->sel_total.p, (int*)c->sel_level_count.p,
-                c->cap_sel, batch, c->tk_scratch.p);
+                (unsigned*)c->hist.p, (RawKey*)c->sel.p, (int*)c->sel_total.p, c->cap_sel, batch, c->tk.p);
     list = (const RawKey*)c->sel.p;
     list_total = (const int*)c->sel_total.p;
     cap_list = c->cap_sel;
@@ -1520,7 +1525,7 @@ void hess_destroy(hess_ctx* c) {
   stager_stop(c->sg);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
-                    &c->sel_level_count, &c->tk_scratch, &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
+                    &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
   for (DevBuf* b : bufs) release(*b);
   release(c->h_keys, true);

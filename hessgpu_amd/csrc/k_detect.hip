@@ -22,6 +22,7 @@
 
 #include "hess_dev.h"
 #include "hess_devmath.h"
+#include "hess_planes.h"
 
 namespace hess {
 
@@ -39,82 +40,6 @@ struct HessArgs {
   float norm[kMaxLev];  // sigma_l^4 (host passes sigma^2, wrapper squares it: ProgramCU.cu:592)
 };
 
-__device__ __forceinline__ float tex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
-
-// neighbour lanes by DPP wave shifts (one VALU move each; no LDS crossbar round trip)
-__device__ __forceinline__ float lane_prev(float v) {  // lane i <- lane i-1 (lane 0: 0)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_next(float v) {  // lane i <- lane i+1 (lane 63: 0)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
-}
-
-// 4 pixels per thread, 16-byte loads/stores.  Neighbour addressing follows the reference's 1-D
-// linear texture: index +-1 wraps across row ends, anything outside [0, wa*h) reads 0.
-// One plane (src = the Gaussian level, dh = its det-H plane, gt = its gradient plane or null); gid = this thread's
-// 4-pixel group of the plane.
-__device__ __forceinline__ void hessian_rows_body(const float* src, float* dh, float2* gt, int wa, int h, float norm,
-                                                  int gid) {
-  const int groups_per_row = wa >> 2;
-  const int nthreads = groups_per_row * h;
-  if (gid >= nthreads) return;
-  // row = gid / groups_per_row without an integer division: float estimate, then one exact correction step
-  int row = (int)(((float)gid + 0.5f) * (1.0f / (float)groups_per_row));
-  int rem = gid - row * groups_per_row;
-  if (rem < 0) { row--; rem += groups_per_row; }
-  else if (rem >= groups_per_row) { row++; rem -= groups_per_row; }
-  const int x = rem << 2;
-  const int n = wa * h;
-  const int idx = row * wa + x;
-
-  // Rows idx-wa, idx, idx+wa as 16-byte loads.  The +-1 neighbours are, in the reference's 1-D
-  // addressing, simply the adjacent thread's outer elements (also across a row end), so they come
-  // from the neighbouring lanes; only the first/last lane of a wavefront (or of the plane) loads them.
-  float U[6], M[6], D[6];
-  {
-    const float4 m = *reinterpret_cast<const float4*>(src + idx);
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int iu = row >= 1 ? idx - wa : idx, id = row + 1 < h ? idx + wa : idx;
-    const float4 uq = *reinterpret_cast<const float4*>(src + iu);
-    const float4 dq = *reinterpret_cast<const float4*>(src + id);
-    if (row >= 1) u = uq;
-    if (row + 1 < h) d = dq;
-    M[1] = m.x; M[2] = m.y; M[3] = m.z; M[4] = m.w;
-    U[1] = u.x; U[2] = u.y; U[3] = u.z; U[4] = u.w;
-    D[1] = d.x; D[2] = d.y; D[3] = d.z; D[4] = d.w;
-  }
-  {
-    const int lane = threadIdx.x & 63;
-    const float ul = lane_prev(U[4]), ml = lane_prev(M[4]), dl = lane_prev(D[4]);
-    const float ur = lane_next(U[1]), mr = lane_next(M[1]), dr = lane_next(D[1]);
-    U[0] = ul; M[0] = ml; D[0] = dl;
-    U[5] = ur; M[5] = mr; D[5] = dr;
-    // (gid & 63 == lane here: the callers hand consecutive gids to consecutive lanes of whole wavefronts)
-    if (lane == 0) {
-      U[0] = tex1(src, n, idx - wa - 1); M[0] = tex1(src, n, idx - 1); D[0] = tex1(src, n, idx + wa - 1);
-    }
-    if (lane == 63 || gid == nthreads - 1) {
-      U[5] = tex1(src, n, idx - wa + 4); M[5] = tex1(src, n, idx + 4); D[5] = tex1(src, n, idx + wa + 4);
-    }
-  }
-  float hv[4];
-  float2 gv[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const float v11 = U[j], v12 = U[j + 1], v13 = U[j + 2];
-    const float v21 = M[j], v22 = M[j + 1], v23 = M[j + 2];
-    const float v31 = D[j], v32 = D[j + 1], v33 = D[j + 2];
-    hv[j] = dm_deth(v11, v12, v13, v21, v22, v23, v31, v32, v33, norm);  // ProgramCU.cu:536-553
-    if (gt) gv[j] = dm_grad_theta(v12, v21, v23, v32);                   // :556-559
-  }
-  *reinterpret_cast<float4*>(dh + idx) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-  if (gt) {
-    float2* g = gt + idx;
-    *reinterpret_cast<float4*>(g) = make_float4(gv[0].x, gv[0].y, gv[1].x, gv[1].y);
-    *reinterpret_cast<float4*>(g + 2) = make_float4(gv[2].x, gv[2].y, gv[3].x, gv[3].y);
-  }
-}
-
 __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
   const int z = blockIdx.y;  // l * batch + b
   const int l = a.level_first + z / a.batch, b = z % a.batch;
@@ -131,31 +56,8 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
 // adjacent lanes, and from explicit 1-D-indexed loads at row ends and wavefront edges.
 // det-H of one level of every octave in a single launch (the octaves' top levels: nobody's source level, so no
 // Gaussian launch computes it on the side).  1 thread = 4 px x 4 rows; neighbour columns from the adjacent lanes.
-struct LevelNorms { float v[kMaxLev]; };
-
-// det-H (+ gradient/theta) of levels 0 .. nlv-1 of octaves >= first_oct from HBM: the levels the level-chain launches
-// (gauss_chain_kernel, k_gauss.hip) produce without their det-H / gradient planes.  blk -> (octave, level, 256 groups).
-__device__ __forceinline__ void hessian_low_levels(const Geom& g, const float* gauss, float* deth, float2* got,
-                                                   const LevelNorms& nm, int first_oct, int nlv, int blk, int b) {
-  int o = first_oct, nb = 0;
-  for (; o < g.noct; o++) {
-    nb = ((g.o[o].wa >> 2) * g.o[o].h + 255) >> 8;
-    if (blk < nb * nlv) break;
-    blk -= nb * nlv;
-  }
-  if (o >= g.noct) return;
-  const int lvl = blk / nb, pb = blk - lvl * nb;
-  const int n = g.o[o].plane;
-  const long long poff = g.o[o].lvl_off + ((long long)lvl * g.B + b) * n;
-  float2* gt = (lvl >= 1 && lvl <= g.dog) ? got + g.o[o].got_off + ((long long)(lvl - 1) * g.B + b) * n : nullptr;
-  hessian_rows_body(gauss + poff, deth + poff, gt, g.o[o].wa, g.o[o].h, nm.v[lvl], pb * 256 + (int)threadIdx.x);
-}
-
-// main_blocks: the workgroups of the top-level part (all octaves); the workgroups after them do levels 0 .. low_nlv-1 of
-// octaves >= low_first (hessian_low_levels).
 __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm,
-                                                            uint4* zero, long long zero_n, int main_blocks, int low_first,
-                                                            int low_nlv, float2* got, LevelNorms nm) {
+                                                            uint4* zero, long long zero_n) {
   // On the side: clear what the detection stages expect zeroed (overflow words, row counts, top-K histogram, extrema
   // masks: one allocation, hess_pipeline.hip) -- a grid-stride fill by this launch's threads instead of a fill
   // launch of its own in the dependent chain.
@@ -163,10 +65,6 @@ __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float*
     const long long nthr = (long long)gridDim.x * gridDim.y * 256;
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_n; i += nthr)
       zero[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  if ((int)blockIdx.x >= main_blocks) {  // (workgroup-uniform)
-    hessian_low_levels(g, gauss, deth, got, nm, low_first, low_nlv, (int)blockIdx.x - main_blocks, (int)blockIdx.y);
-    return;
   }
   int blk = blockIdx.x, o = 0;  // block -> octave: octaves back to back, whole blocks each (uniform scalar walk)
   for (; o < g.noct - 1; o++) {
@@ -651,15 +549,130 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
 // Extrema scan pass 2: one thread per detection.  Thread i of image b finds its row by binary search
 // in the exclusive row offsets, its column as the (i - offset)-th set bit of the row's mask words,
 // recomputes the keypoint (all lanes busy) and writes raw[i]: row-major order by construction.
-__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, const float* gauss,
+__device__ int apply_level_limits(int* lc, int nlev, const LimitParams& lp, bool generation_stage);
+
+// Rows per image up to which the scatter pass scans the row counts itself, in LDS (1080p: 6 423 rows; a 4096^2 image has
+// 24 552 and keeps the separate row_scan_kernel).
+constexpr int SC_MAXROWS = 8192;
+
+// SCAN = true: every workgroup first turns the image's row counts into exclusive offsets in LDS -- level totals, the
+// -tc level rules, one workgroup scan, exactly row_scan_kernel's steps -- instead of reading the offsets a launch of
+// its own would have left in HBM: a single-workgroup kernel (12 us) less in the batch's dependent chain for 2 - 3 us
+// of redundant work per workgroup on L2-resident counts; the searches below then run on LDS.  Workgroup 0 of the
+// image posts the totals (raw_total, level_count, the overflow word).
+template <bool SCAN>
+__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, LimitParams lp, const float* gauss,
                                                               const float* deth, const uint64_t* rowmask,
-                                                              const int* rowoff, const int* raw_total,
-                                                              RawKey* raw, int cap_raw, unsigned* hist, int topk) {
+                                                              const int* rowoff_or_cnt, int* raw_total, int* level_count,
+                                                              int* overflow, RawKey* raw, int cap_raw, unsigned* hist,
+                                                              int topk) {
+  __shared__ int s_off[SCAN ? SC_MAXROWS : 1];
+  __shared__ int s_lc[kMaxOct * kMaxDog], s_keep[kMaxOct * kMaxDog], s_h[kMaxOct], s_base[kMaxOct], s_wsum[4], s_total;
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int n = raw_total[b];
+  int n;
+  const int* off;
+  if (SCAN) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int* cnt = rowoff_or_cnt + (long long)b * g.NR;
+    constexpr int RC = SC_MAXROWS / 256;  // rows per thread at most
+    {  // counts -> LDS, coalesced; all loads of a thread in flight before its first LDS store (the counts are L2-resident)
+      int v[RC];
+#pragma unroll
+      for (int u = 0; u < RC; u++) v[u] = (tid + u * 256 < g.NR) ? cnt[tid + u * 256] : 0;
+#pragma unroll
+      for (int u = 0; u < RC; u++) if (tid + u * 256 < g.NR) s_off[tid + u * 256] = v[u];
+    }
+    for (int k = tid; k < g.nlev; k += 256) s_lc[k] = 0;
+    if (tid < g.noct) { s_h[tid] = g.o[tid].h; s_base[tid] = g.o[tid].row_base; }
+    __syncthreads();
+    // a thread owns `per` consecutive rows of the list order, held in registers; the level of a row follows from
+    // walking the level boundaries (levels are consecutive in list order)
+    const int per = (g.NR + 255) >> 8;
+    const int r0 = min(tid * per, g.NR), r1 = min(g.NR, r0 + per);
+    int cc[RC], lis[RC];
+#pragma unroll
+    for (int u = 0; u < RC; u++) cc[u] = (u < per && r0 + u < r1) ? s_off[r0 + u] : 0;
+    {
+      int o = 0;
+      const int rq = min(r0, g.NR - 1);
+      for (int k = 1; k < g.noct; k++) if (s_base[k] <= rq) o = k;
+      const int rel = rq - s_base[o];
+      int lm = rel / s_h[o];
+      int li = o * g.dog + lm, left = s_h[o] - (rel - lm * s_h[o]), oo = o;  // rows left in the level, this one included
+#pragma unroll
+      for (int u = 0; u < RC; u++) {
+        lis[u] = li;
+        if (--left == 0) {
+          li++;
+          if (++lm == g.dog) { lm = 0; oo++; }
+          left = oo < g.noct ? s_h[oo] : 0x7fffffff;
+        }
+      }
+    }
+    // level totals (the -tc rules work on them; without a rule every level stays and only workgroup 0, which posts the
+    // totals, needs them)
+    const bool limits = lp.threshold > 0 && lp.method != 3;
+    if (limits || blockIdx.x == 0) {  // (workgroup-uniform)
+      int run_level = -1, run = 0;
+#pragma unroll
+      for (int u = 0; u < RC; u++) {
+        if (cc[u]) {
+          if (lis[u] != run_level) {
+            if (run) atomicAdd(&s_lc[run_level], run);
+            run_level = lis[u]; run = 0;
+          }
+          run += cc[u];
+        }
+      }
+      if (run) atomicAdd(&s_lc[run_level], run);
+      __syncthreads();
+      if (tid == 0) {
+        int before[kMaxOct * kMaxDog];
+        for (int k = 0; k < g.nlev; k++) before[k] = s_lc[k];
+        const int total = apply_level_limits(s_lc, g.nlev, lp, true);
+        for (int k = 0; k < g.nlev; k++) {
+          s_keep[k] = (s_lc[k] == before[k]);  // a level is either kept whole or dropped
+          if (blockIdx.x == 0) level_count[b * g.nlev + k] = s_lc[k];
+        }
+        if (blockIdx.x == 0) {
+          raw_total[b] = total < cap_raw ? total : cap_raw;
+          if (total > cap_raw) atomicMax(overflow, total);
+        }
+      }
+      __syncthreads();
+      if (limits) {
+#pragma unroll
+        for (int u = 0; u < RC; u++) cc[u] = s_keep[min(lis[u], g.nlev - 1)] ? cc[u] : 0;  // dropped rows count 0: offsets stay monotone
+      }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < RC; u++) mine += cc[u];
+    int inc = mine;  // inclusive scan over the 256 threads: wavefront scan + four wavefront sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    int e = inc - mine;
+    for (int k = 0; k < wv; k++) e += s_wsum[k];
+    if (tid == 0) s_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+    for (int u = 0; u < RC; u++) {  // counts -> exclusive offsets, in place
+      if (u < per && r0 + u < r1) s_off[r0 + u] = e;
+      e += cc[u];
+    }
+    __syncthreads();
+    n = min(s_total, cap_raw);
+    off = s_off;
+  } else {
+    n = raw_total[b];
+    off = rowoff_or_cnt + (long long)b * g.NR;
+  }
   if (i >= n) return;
-  const int* off = rowoff + (long long)b * g.NR;
   // the detection's row is the LAST row whose exclusive offset is <= i (offsets are non-decreasing;
   // empty rows and rows of levels dropped by -tc count 0 and so never qualify as the last one)
   // eight-way search: the seven probes of a step are independent loads (one round trip instead of three)
@@ -915,20 +928,22 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
 
 // =============================== top-K =======================================================
 
-// Top-K in two wide launches (rounds 1-2: one 1024-thread workgroup per image did the whole selection -- 33 us on the
-// critical path of a single 1080p image, 0.24 ms for a 4096^2 image with 2.6e5 detections).  The list is cut into chunks of
-// TK_CHUNK entries, one workgroup each:
-//   topk_count_kernel    finds the cut bin and the number of tied entries to keep from the 15-bit histogram (every
-//                        workgroup with work for itself: 128 KB from L2), classifies its chunk from the keys alone and
-//                        posts (sure keeps, ties) of the chunk; the image's first workgroup also posts cut / need and
-//                        clears the per-level counts;
-//   topk_scatter_kernel  sums the counts of the chunks before its own (list order = chunk order), classifies again, one
-//                        workgroup scan gives every thread its tie rank and output position -- of the first T ties
-//                        min(T, need) are kept -- and the kept entries are copied in order.
+// Top-K in ONE wide launch (rounds 1-2: one 1024-thread workgroup per image did the whole selection -- 33 us on the
+// critical path of a single 1080p image, 0.24 ms for a 4096^2 image with 2.6e5 detections; round 3: a counting and a
+// copying launch).  The list is cut into chunks of TK_CHUNK entries, one workgroup each, chunk numbers handed out by a
+// ticket counter in ARRIVAL order (so every workgroup with a lower chunk number is already running: the look-back
+// below cannot wait for a workgroup that has not started, whatever the order the hardware dispatches them in):
+//   1. cut bin and number of tied entries to keep, from the 15-bit histogram (every workgroup for itself: 128 KB, L2);
+//   2. the chunk's entries are classified from their keys alone; (sure keeps, ties) of the chunk are PUBLISHED as one
+//      64-bit word before the workgroup waits for anything;
+//   3. look-back: the words of the chunks before this one are awaited and summed (a predecessor publishes after step
+//      2, which depends on nothing: bounded wait);
+//   4. one workgroup scan gives every thread its tie rank and output position -- of the first T ties min(T, need) are
+//      kept -- and the kept entries are copied in list order; the last chunk in use posts the kept total.
 // Same result as before: the K largest abs(half(response)), ties at the cut to the lower list index, list order kept.
+// ticket / state / sel_level_count arrive zeroed (they live in the batch's cleared block, hess_pipeline.hip).
 constexpr int TK_PER = 4, TK_CHUNK = 1024 * TK_PER;
 
-struct TopkChunk { int sure, ties; };
 
 // cut bin and number of ties to keep, by all 1024 threads of a workgroup; n >= K.  Result in s_cut / s_need (LDS).
 __device__ __forceinline__ void topk_find_cut(const unsigned* h, int K, int* lds, int* s_cut, int* s_need) {
@@ -981,68 +996,57 @@ __device__ __forceinline__ void topk_classify(const RawKey* in, int i0, int n, i
   *surem = sm; *tiem = tm;
 }
 
-__global__ __launch_bounds__(1024) void topk_count_kernel(Geom g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
-                                                          const unsigned* hist, TopkChunk* chunks, int* cutbuf,
-                                                          int* sel_level_count, int nchunk) {
-  __shared__ int lds[64];
-  __shared__ int s_cut, s_need;
-  const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
-  const int n = raw_total[b];
-  if (ck * TK_CHUNK >= n && ck != 0) return;  // (workgroup-uniform) nothing in this chunk
-  if (tid == 0) { s_cut = -1; s_need = 0; }
-  __syncthreads();
-  if (n >= K) topk_find_cut(hist + (long long)b * kHistBins, K, lds, &s_cut, &s_need);  // SelectTopK is skipped below K detections
-  const int cut = s_cut, need = s_need;
-  if (ck == 0) {
-    if (tid == 0) { cutbuf[2 * b] = cut; cutbuf[2 * b + 1] = need; }
-    for (int i = tid; i < g.nlev; i += 1024) sel_level_count[b * g.nlev + i] = 0;
-  }
-  uint32_t surem, tiem;
-  topk_classify(raw + (long long)b * cap_raw, ck * TK_CHUNK + tid * TK_PER, n, cut, &surem, &tiem);
-  int etie, esure, ttie, tsure;
-  block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
-  if (tid == 0) { chunks[(long long)b * nchunk + ck].sure = tsure; chunks[(long long)b * nchunk + ck].ties = ttie; }
-}
+constexpr unsigned long long TK_FLAG = 1ull << 40;
 
-__global__ __launch_bounds__(1024) void topk_scatter_kernel(Geom g, const RawKey* raw, const int* raw_total, int cap_raw,
-                                                            const TopkChunk* chunks, const int* cutbuf, RawKey* sel,
-                                                            int* sel_total, int* sel_level_count, int cap_sel, int nchunk) {
+__global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
+                                                           const unsigned* hist, int* ticket, unsigned long long* state,
+                                                           RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel,
+                                                           int nchunk) {
   __shared__ int lds[64];
   __shared__ int lc[kMaxOct * kMaxDog];
-  __shared__ int s_sure0, s_ties0, s_sure_all, s_ties_all;
-  const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_cut, s_need, s_ck, s_sure0, s_ties0;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid == 0) { s_ck = atomicAdd(&ticket[b], 1); s_cut = -1; s_need = 0; }
+  __syncthreads();
+  const int ck = s_ck;
   const int n = raw_total[b];
-  if (ck * TK_CHUNK >= n && ck != 0) return;  // (workgroup-uniform)
+  const int used = (n + TK_CHUNK - 1) / TK_CHUNK;
+  if (ck >= used && ck != 0) return;  // (workgroup-uniform) nothing in this chunk; nobody waits for it
   const RawKey* in = raw + (long long)b * cap_raw;
   RawKey* out = sel + (long long)b * cap_sel;
-  const int cut = cutbuf[2 * b], need = cutbuf[2 * b + 1];
   for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
-  // counts of the chunks before this one (and, for the image's first workgroup, of all of them: the kept total)
-  const int used = (n + TK_CHUNK - 1) / TK_CHUNK;
-  {
-    int ps = 0, pt = 0, as = 0, at = 0;
-    for (int k = tid; k < used; k += 1024) {
-      const TopkChunk c = chunks[(long long)b * nchunk + k];
-      if (k < ck) { ps += c.sure; pt += c.ties; }
-      as += c.sure; at += c.ties;
-    }
-    int e0, e1, t0, t1, t2, t3;
-    block_scan2(ps, pt, &e0, &e1, &t0, &t1, lds);
-    __syncthreads();
-    block_scan2(as, at, &e0, &e1, &t2, &t3, lds);
-    if (tid == 0) { s_sure0 = t0; s_ties0 = t1; s_sure_all = t2; s_ties_all = t3; }
-    __syncthreads();
-  }
-  const int ties0 = s_ties0, kept0 = s_sure0 + min(ties0, need);
-  if (ck == 0 && tid == 0) {
-    const int kept = s_sure_all + min(s_ties_all, need);
-    sel_total[b] = kept < cap_sel ? kept : cap_sel;
-  }
+  if (n >= K) topk_find_cut(hist + (long long)b * kHistBins, K, lds, &s_cut, &s_need);  // SelectTopK is skipped below K detections
+  __syncthreads();
+  const int cut = s_cut, need = s_need;
   const int i0 = ck * TK_CHUNK + tid * TK_PER;
   uint32_t surem, tiem;
   topk_classify(in, i0, n, cut, &surem, &tiem);
   int etie, esure, ttie, tsure;
   block_scan2(__popc(tiem), __popc(surem), &etie, &esure, &ttie, &tsure, lds);
+  unsigned long long* st = state + (long long)b * nchunk;
+  if (tid == 0)
+    __hip_atomic_store(&st[ck], TK_FLAG | ((unsigned long long)tsure << 20) | (unsigned long long)ttie, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // look-back over the chunks before this one
+  int ps = 0, pt = 0;
+  for (int k = tid; k < ck; k += 1024) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(&st[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & TK_FLAG));
+    ps += (int)((v >> 20) & 0xFFFFFu);
+    pt += (int)(v & 0xFFFFFu);
+  }
+  {
+    int e0, e1, t0, t1;
+    __syncthreads();
+    block_scan2(ps, pt, &e0, &e1, &t0, &t1, lds);
+    if (tid == 0) { s_sure0 = t0; s_ties0 = t1; }
+    __syncthreads();
+  }
+  const int ties0 = s_ties0, kept0 = s_sure0 + min(ties0, need);
+  if (tid == 0 && (ck == used - 1 || used == 0)) {  // the last chunk in use knows the kept total
+    const int kept = s_sure0 + tsure + min(ties0 + ttie, need);
+    sel_total[b] = kept < cap_sel ? kept : cap_sel;
+  }
   int tseen = ties0 + etie;                                  // ties before this thread's entries
   int pos = kept0 + esure + (min(tseen, need) - min(ties0, need));
   int run_level = -1, run = 0;  // kept entries per level: one LDS atomic per run of equal levels, not per entry
@@ -1069,6 +1073,7 @@ __global__ __launch_bounds__(1024) void topk_scatter_kernel(Geom g, const RawKey
     pos++;                                                                   \
   }
   static_assert(TK_PER == 4 && sizeof(RawKey) == 32 && offsetof(RawKey, level_index) == 0, "RawKey as two uint4, four per thread");
+  static_assert(TK_CHUNK < (1 << 20), "chunk counts fit the published word");
   HESS_TK_LOAD(0) HESS_TK_LOAD(1) HESS_TK_LOAD(2) HESS_TK_LOAD(3)
   HESS_TK_STORE(0) HESS_TK_STORE(1) HESS_TK_STORE(2) HESS_TK_STORE(3)
 #undef HESS_TK_LOAD
@@ -1116,17 +1121,11 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 }
 
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
-                          int batch, void* zero, size_t zero_bytes, int low_first, int low_nlv, float* got,
-                          const float* norms) {
-  if (low_first < 0 || low_first > g.noct || low_nlv <= 0) { low_first = g.noct; low_nlv = 0; }
-  int blocks = 0, low_blocks = 0;
+                          int batch, void* zero, size_t zero_bytes) {
+  int blocks = 0;
   for (int o = 0; o < g.noct; o++) blocks += ((g.o[o].wa >> 2) * ((g.o[o].h + 3) >> 2) + 255) >> 8;
-  for (int o = low_first; o < g.noct; o++) low_blocks += low_nlv * (((g.o[o].wa >> 2) * g.o[o].h + 255) >> 8);
-  LevelNorms nm;
-  for (int l = 0; l < kMaxLev; l++) nm.v[l] = (norms && l < g.dog + 2) ? norms[l] : 0.0f;
-  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks + low_blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm,
-                     reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16), blocks, low_first, low_nlv,
-                     reinterpret_cast<float2*>(got), nm);
+  hipLaunchKernelGGL(hessian_rows4_kernel, dim3(blocks, batch), dim3(256), 0, st, g, gauss, deth, level, norm,
+                     reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16));
 }
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
@@ -1164,30 +1163,39 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
                      raw_total, cap_raw, overflow);
 }
 
-void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                            const float* deth, const uint64_t* rowmask, const int* rowoff, const int* raw_total,
-                            RawKey* raw, int cap_raw, int batch, unsigned* hist, int topk) {
-  hipLaunchKernelGGL(extrema_scatter_kernel, dim3((cap_raw + 255) / 256, batch), dim3(256), 0, st, g, dp, gauss, deth,
-                     rowmask, rowoff, raw_total, raw, cap_raw, hist, topk);
+bool extrema_scatter_scans(const Geom& g) { return g.NR <= SC_MAXROWS; }
+
+void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const LimitParams& lp, const float* gauss,
+                            const float* deth, const uint64_t* rowmask, const int* rowcnt, int* rowoff, int* level_count,
+                            int* raw_total, int* overflow, RawKey* raw, int cap_raw, int batch, unsigned* hist, int topk) {
+  const dim3 grid((cap_raw + 255) / 256, batch);
+  if (extrema_scatter_scans(g)) {  // the scatter workgroups scan the row counts themselves (LDS)
+    hipLaunchKernelGGL(extrema_scatter_kernel<true>, grid, dim3(256), 0, st, g, dp, lp, gauss, deth, rowmask, rowcnt,
+                       raw_total, level_count, overflow, raw, cap_raw, hist, topk);
+    return;
+  }
+  launch_row_scan(st, g, lp, rowcnt, rowoff, level_count, raw_total, cap_raw, overflow, batch);
+  hipLaunchKernelGGL(extrema_scatter_kernel<false>, grid, dim3(256), 0, st, g, dp, lp, gauss, deth, rowmask, rowoff,
+                     raw_total, level_count, overflow, raw, cap_raw, hist, topk);
 }
 
 int topk_chunks(int cap_raw) { return (cap_raw + TK_CHUNK - 1) / TK_CHUNK; }
 
+// scratch (topk_scratch_bytes; must arrive zeroed): [ticket: batch ints, padded to 8 bytes][state: batch x nchunk
+// 64-bit words][sel_level_count: batch x nlev ints]
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
-                 unsigned* hist, RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel, int batch,
-                 void* scratch) {
-  // hist: zeroed with the batch's detection buffers, counted by extrema_scatter_kernel.  scratch: topk_scratch_bytes()
+                 unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch) {
   const int nchunk = topk_chunks(cap_raw);
-  int* cutbuf = reinterpret_cast<int*>(scratch);
-  TopkChunk* chunks = reinterpret_cast<TopkChunk*>(cutbuf + 2 * batch);
-  hipLaunchKernelGGL(topk_count_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist,
-                     chunks, cutbuf, sel_level_count, nchunk);
-  hipLaunchKernelGGL(topk_scatter_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, raw, raw_total, cap_raw, chunks,
-                     cutbuf, sel, sel_total, sel_level_count, cap_sel, nchunk);
+  int* ticket = reinterpret_cast<int*>(scratch);
+  unsigned long long* state = reinterpret_cast<unsigned long long*>(ticket + ((batch + 1) & ~1));
+  int* sel_level_count = reinterpret_cast<int*>(state + (size_t)batch * nchunk);
+  hipLaunchKernelGGL(topk_select_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist,
+                     ticket, state, sel, sel_total, sel_level_count, cap_sel, nchunk);
 }
 
-size_t topk_scratch_bytes(int cap_raw, int batch) {
-  return (size_t)batch * (2 * sizeof(int) + (size_t)topk_chunks(cap_raw) * sizeof(TopkChunk));
+size_t topk_scratch_bytes(int cap_raw, int batch, int nlev) {
+  return (size_t)((batch + 1) & ~1) * sizeof(int) + (size_t)batch * topk_chunks(cap_raw) * sizeof(unsigned long long) +
+         (size_t)batch * nlev * sizeof(int);
 }
 
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n) {

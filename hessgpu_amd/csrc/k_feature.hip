@@ -44,6 +44,144 @@ __device__ __forceinline__ void level_of(const Geom& g, int li, int* o, int* l) 
   *l = li - (*o) * g.dog + 1;
 }
 
+// ================================= feature scan ==============================================
+
+// exclusive scan over the workgroup (any number of whole wavefronts up to 16); lds: 16 ints
+__device__ __forceinline__ int block_scan1(int a, int* total, int* lds) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int ia = a;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int na = __shfl_up(ia, d);
+    if (lane >= d) ia += na;
+  }
+  __syncthreads();
+  if (lane == 63) lds[wv] = ia;
+  __syncthreads();
+  int oa = 0, sa = 0;
+  for (int k = 0; k < nw; k++) {
+    if (k < wv) oa += lds[k];
+    sa += lds[k];
+  }
+  *total = sa;
+  return oa + ia - a;
+}
+
+// Multi-orientation expansion of ONE image by the calling workgroup (all its threads): prefix sum of the orientation
+// counts, feature -> (keypoint, rank) table, -tc rule on the expanded counts, and -- by the image that finishes last --
+// the packed output layout of the batch.  (Run by the orientation launch's last workgroup per image instead of a launch
+// of its own, it cost more than it saved: the scan's registers took the orientation kernel from eight to five
+// wavefronts per SIMD and a 256-thread workgroup scans slower than a 1024-thread one -- 37 us against 16 + 13.)
+struct FeatScan {
+  LimitParams lp;
+  int multi;
+  int* foffset;
+  int* fsrc;
+  int* feat_total;
+  int* feat_first;
+  int cap_feat;
+  int* overflow;    // the batch's four overflow words (the scan raises word 1); word 8 of the same zeroed block counts the
+                    // images that have finished, so that the last one can lay out the packed output of the whole batch
+  int* img_base;
+  int* host_small;
+};
+
+__device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan& fs, const RawKey* list, const int* list_total,
+                                                   int cap_list, const int* ocount, int b, int nimg) {
+  const LimitParams& lp = fs.lp;
+  const int multi = fs.multi, cap_feat = fs.cap_feat;
+  int* const foffset = fs.foffset; int* const fsrc = fs.fsrc; int* const feat_total = fs.feat_total;
+  int* const feat_first = fs.feat_first; int* const overflow = fs.overflow; int* const img_base = fs.img_base;
+  int* const host_small = fs.host_small;
+  __shared__ int lds[64];
+  __shared__ int lc[kMaxOct * kMaxDog];
+  __shared__ int carry;
+  const int tid = threadIdx.x, NTH = blockDim.x;
+  const int n = list_total[b];
+  for (int i = tid; i < g.nlev; i += NTH) lc[i] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  // A thread takes up to 16 consecutive keypoints per pass (their counts and levels read with independent loads),
+  // so a list of 16 k keypoints is one pass with one workgroup scan.
+  constexpr int FC = 16;
+  for (int base = 0; base < n; base += NTH * FC) {
+    const int left = n - base;
+    const int per = left >= NTH * FC ? FC : (left + NTH - 1) / NTH;  // uniform over the workgroup
+    const int i0 = base + tid * per;
+    int cc[FC], lv[FC], mine = 0;
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      const bool in = u < per && i0 + u < n;
+      const long long at = (long long)b * cap_list + (in ? i0 + u : 0);
+      cc[u] = in ? (multi ? ocount[at] : 1) : 0;
+      lv[u] = list[at].level_index;
+    }
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      if (cc[u]) atomicAdd(&lc[lv[u]], cc[u]);
+      mine += cc[u];
+    }
+    int tot;
+    int e = block_scan1(mine, &tot, lds);
+    const int cb = carry;
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      if (u < per && i0 + u < n) {
+        foffset[(long long)b * cap_list + i0 + u] = cb + e;
+        // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
+        // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
+        for (int k = 0; k < cc[u]; k++)
+          if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = (i0 + u) * 4 + k;
+        e += cc[u];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) carry = cb + tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int total = carry, first = 0;
+    // LimitFeatureCount(1) (SiftPyramid.cpp:143,201-278): only after the multi-orientation reshape
+    if (multi && lp.threshold > 0 && lp.method != 3) {
+      if (lp.method == 2) {
+        int i = 0, nf = 0;
+        for (; (nf < lp.threshold) && (i < g.nlev); ++i) nf += lc[i];
+        if (nf < total) total = nf;
+      } else {
+        int i = 0;
+        while (i < g.nlev && (total - lc[i]) > lp.threshold) { total -= lc[i]; first += lc[i]; i++; }
+      }
+    }
+    if (total > cap_feat) { atomicMax(overflow + 1, total); total = cap_feat; }
+    feat_total[b] = total;
+    feat_first[b] = first;
+    // Packed output offsets of the batch (images back to back), by whichever workgroup finishes last.  With
+    // host-direct delivery the offsets and the overflow words also go to the pinned host block the caller reads once
+    // the stream has drained (no device->host copy commands).
+    __threadfence();
+    if (atomicAdd(overflow + 8, 1) == nimg - 1) {
+      __threadfence();
+      int acc = 0;
+      for (int i = 0; i < nimg; i++) {
+        img_base[i] = acc;
+        if (host_small) host_small[i] = acc;
+        acc += __hip_atomic_load(feat_total + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      img_base[nimg] = acc;
+      if (host_small) {
+        host_small[nimg] = acc;
+        for (int i = 0; i < 4; i++)
+          host_small[nimg + 1 + i] = __hip_atomic_load(overflow + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, FeatScan fs, const RawKey* list, const int* list_total,
+                                                            int cap_list, const int* ocount) {
+  feature_scan_image(g, fs, list, list_total, cap_list, ocount, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ================================= orientation ===============================================
 
 // e^x for the Gaussian windows of the orientation and descriptor stages: same operations and results as dm_expf() on -87 <= x <= 88 (there
@@ -274,119 +412,6 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams o
       r.x = posX; r.y = posY; r.z = scale; r.w = kw_bits;
       recs[(long long)b * cap_list + i] = r;
       ocount[(long long)b * cap_list + i] = ocnt;
-    }
-  }
-}
-
-// ================================= feature scan ==============================================
-
-__device__ __forceinline__ int block_scan1(int a, int* total, int* lds) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int ia = a;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int na = __shfl_up(ia, d);
-    if (lane >= d) ia += na;
-  }
-  __syncthreads();
-  if (lane == 63) lds[wv] = ia;
-  __syncthreads();
-  int oa = 0, sa = 0;
-  for (int k = 0; k < 16; k++) {
-    if (k < wv) oa += lds[k];
-    sa += lds[k];
-  }
-  *total = sa;
-  return oa + ia - a;
-}
-
-__global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, LimitParams lp, int multi, const RawKey* list,
-                                                            const int* list_total, int cap_list, const int* ocount,
-                                                            int* foffset, int* fsrc, int* feat_total,
-                                                            int* feat_first, int cap_feat, int* overflow,
-                                                            int* img_base, int* host_small) {
-  // overflow: the batch's four overflow words (this kernel raises word 1); word 8 of the same zeroed block counts
-  // the workgroups that have finished, so that the last one can lay out the packed output of the whole batch
-  __shared__ int lds[64];
-  __shared__ int lc[kMaxOct * kMaxDog];
-  __shared__ int carry;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = list_total[b];
-  for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  // A thread takes up to 16 consecutive keypoints per pass (their counts and levels read with independent loads),
-  // so a list of 16 k keypoints is one pass with one workgroup scan.
-  constexpr int FC = 16;
-  for (int base = 0; base < n; base += 1024 * FC) {
-    const int left = n - base;
-    const int per = left >= 1024 * FC ? FC : (left + 1023) >> 10;  // uniform over the workgroup
-    const int i0 = base + tid * per;
-    int cc[FC], lv[FC], mine = 0;
-#pragma unroll
-    for (int u = 0; u < FC; u++) {
-      const bool in = u < per && i0 + u < n;
-      const long long at = (long long)b * cap_list + (in ? i0 + u : 0);
-      cc[u] = in ? (multi ? ocount[at] : 1) : 0;
-      lv[u] = list[at].level_index;
-    }
-#pragma unroll
-    for (int u = 0; u < FC; u++) {
-      if (cc[u]) atomicAdd(&lc[lv[u]], cc[u]);
-      mine += cc[u];
-    }
-    int tot;
-    int e = block_scan1(mine, &tot, lds);
-    const int cb = carry;
-#pragma unroll
-    for (int u = 0; u < FC; u++) {
-      if (u < per && i0 + u < n) {
-        foffset[(long long)b * cap_list + i0 + u] = cb + e;
-        // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
-        // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
-        for (int k = 0; k < cc[u]; k++)
-          if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = (i0 + u) * 4 + k;
-        e += cc[u];
-      }
-    }
-    __syncthreads();
-    if (tid == 0) carry = cb + tot;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    int total = carry, first = 0;
-    // LimitFeatureCount(1) (SiftPyramid.cpp:143,201-278): only after the multi-orientation reshape
-    if (multi && lp.threshold > 0 && lp.method != 3) {
-      if (lp.method == 2) {
-        int i = 0, nf = 0;
-        for (; (nf < lp.threshold) && (i < g.nlev); ++i) nf += lc[i];
-        if (nf < total) total = nf;
-      } else {
-        int i = 0;
-        while (i < g.nlev && (total - lc[i]) > lp.threshold) { total -= lc[i]; first += lc[i]; i++; }
-      }
-    }
-    if (total > cap_feat) { atomicMax(overflow + 1, total); total = cap_feat; }
-    feat_total[b] = total;
-    feat_first[b] = first;
-    // Packed output offsets of the batch (images back to back), by whichever workgroup finishes last.  With
-    // host-direct delivery the offsets and the overflow words also go to the pinned host block the caller reads once
-    // the stream has drained (no device->host copy commands).
-    __threadfence();
-    if (atomicAdd(overflow + 8, 1) == (int)gridDim.x - 1) {
-      __threadfence();
-      int acc = 0;
-      for (int i = 0; i < (int)gridDim.x; i++) {
-        img_base[i] = acc;
-        if (host_small) host_small[i] = acc;
-        acc += __hip_atomic_load(feat_total + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      img_base[gridDim.x] = acc;
-      if (host_small) {
-        host_small[gridDim.x] = acc;
-        for (int i = 0; i < 4; i++)
-          host_small[gridDim.x + 1 + i] = __hip_atomic_load(overflow + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
   }
 }
@@ -739,6 +764,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         }
       }
       if (lane < 32) *reinterpret_cast<float4*>(dout + lane * 4) = v;
+      // (streaming stores for the mirror were measured: 0.341 - 0.346 against 0.333 - 0.339 ms per single image, same call)
       if (HOST_MIRROR && dp.hdesc && lane < 32) *reinterpret_cast<float4*>(dp.hdesc + (obase + oidx) * dim + lane * 4) = v;
     }
   }
@@ -760,8 +786,10 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
                          const int* list_total, int cap_list, const int* ocount, int* foffset, int* fsrc,
                          int* feat_total, int* feat_first, int cap_feat, int* overflow, int* img_base, int* host_small,
                          int batch) {
-  hipLaunchKernelGGL(feature_scan_kernel, dim3(batch), dim3(1024), 0, st, g, lp, multi, list, list_total, cap_list,
-                     ocount, foffset, fsrc, feat_total, feat_first, cap_feat, overflow, img_base, host_small);
+  FeatScan fs;
+  fs.lp = lp; fs.multi = multi; fs.foffset = foffset; fs.fsrc = fsrc; fs.feat_total = feat_total; fs.feat_first = feat_first;
+  fs.cap_feat = cap_feat; fs.overflow = overflow; fs.img_base = img_base; fs.host_small = host_small;
+  hipLaunchKernelGGL(feature_scan_kernel, dim3(batch), dim3(1024), 0, st, g, fs, list, list_total, cap_list, ocount);
 }
 
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,

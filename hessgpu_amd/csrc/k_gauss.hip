@@ -24,6 +24,7 @@
 
 #include "hess_dev.h"
 #include "hess_devmath.h"
+#include "hess_planes.h"
 
 namespace hess {
 
@@ -540,18 +541,34 @@ __global__ __launch_bounds__(CNT) void gauss_chain_kernel(ChainArgs a) {
 
 // ---- several independent level launches of the same tap count in one grid (the top levels of all octaves: their
 // sources, level 3 of every octave, are complete once the chain above has run): the tile kernel's body per job ----
+// The workgroups after the last job's do det-H / gradient of the chained octaves' low levels (hessian_low_levels):
+// they, too, only need planes the chain has completed.
 constexpr int kMultiJobs = 8;
 struct MultiArgs {
   GaussArgs j[kMultiJobs];
   int first_block[kMultiJobs + 1];  // job k owns workgroups [first_block[k], first_block[k+1])
-  int njobs;
+  int njobs, batch;
+  // low levels: blocks [first_block[njobs], +low_blocks * batch), image-major
+  int low_first, low_nlv, low_blocks;
+  const float* gauss;
+  float* deth;
+  float2* got;
+  LevelNorms nm;
 };
+struct MultiGeom { Geom g; };
 template <int R>
-__global__ __launch_bounds__(NT) void gauss_multi_kernel(MultiArgs m) {
+__global__ __launch_bounds__(NT) void gauss_multi_kernel(MultiArgs m, MultiGeom mg) {
   __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R>()];
+  const int blk = (int)blockIdx.x;
+  if (blk >= m.first_block[m.njobs]) {  // (workgroup-uniform)
+    const int lb = blk - m.first_block[m.njobs];
+    const int b = lb / m.low_blocks;
+    hessian_low_levels(mg.g, m.gauss, m.deth, m.got, m.nm, m.low_first, m.low_nlv, lb - b * m.low_blocks, b);
+    return;
+  }
   int k = 0;
-  for (int q = 1; q < m.njobs; q++) if ((int)blockIdx.x >= m.first_block[q]) k = q;  // (uniform scalar walk)
-  gauss_tile<R, false, true>(m.j[k], s, (int)blockIdx.x - m.first_block[k]);
+  for (int q = 1; q < m.njobs; q++) if (blk >= m.first_block[q]) k = q;  // (uniform scalar walk)
+  gauss_tile<R, false, true>(m.j[k], s, blk - m.first_block[k]);
 }
 
 template <int R>
@@ -753,11 +770,12 @@ bool launch_gauss_chain(hipStream_t st, const ChainJob& j, int batch) {
 // Level launches with the same tap count and a det-H / gradient plane of their source, all in one grid.
 namespace {
 template <int R>
-void launch_multi_r(hipStream_t st, const MultiArgs& m, int blocks) {
-  hipLaunchKernelGGL((gauss_multi_kernel<R>), dim3(blocks), dim3(NT), 0, st, m);
+void launch_multi_r(hipStream_t st, const MultiArgs& m, const MultiGeom& mg, int blocks) {
+  static_assert(sizeof(MultiArgs) + sizeof(MultiGeom) <= 4000, "kernel argument segment");
+  hipLaunchKernelGGL((gauss_multi_kernel<R>), dim3(blocks), dim3(NT), 0, st, m, mg);
 }
 }  // namespace
-bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch) {
+bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int batch, const LowLevels* low) {
   if (njobs < 1) return true;
   const int r = jobs[0].taps.fw >> 1;
   if (r < 8 || r > 12) return false;
@@ -765,7 +783,10 @@ bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int bat
     if (!jobs[k].deth_src || !jobs[k].got_src || (jobs[k].taps.fw >> 1) != r) return false;
   for (int k0 = 0; k0 < njobs; k0 += kMultiJobs) {
     MultiArgs m;
+    MultiGeom mg;
+    memset(&mg, 0, sizeof(mg));
     m.njobs = njobs - k0 < kMultiJobs ? njobs - k0 : kMultiJobs;
+    m.batch = batch;
     int blocks = 0;
     for (int k = 0; k < m.njobs; k++) {
       m.j[k] = job_args(jobs[k0 + k], batch);
@@ -774,12 +795,24 @@ bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int bat
     }
     for (int k = m.njobs; k < kMultiJobs; k++) { m.j[k] = m.j[0]; m.first_block[k] = blocks; }
     m.first_block[kMultiJobs] = blocks;
+    m.first_block[m.njobs] = blocks;
+    m.low_first = 0; m.low_nlv = 0; m.low_blocks = 1; m.gauss = nullptr; m.deth = nullptr; m.got = nullptr;
+    for (int l = 0; l < kMaxLev; l++) m.nm.v[l] = 0.0f;
+    if (low && low->nlv > 0 && k0 + kMultiJobs >= njobs) {  // with the last group of jobs
+      mg.g = *low->g;
+      m.low_first = low->first_oct; m.low_nlv = low->nlv;
+      m.gauss = low->gauss; m.deth = low->deth; m.got = reinterpret_cast<float2*>(low->got);
+      for (int l = 0; l < kMaxLev && l < low->g->dog + 2; l++) m.nm.v[l] = low->norms[l];
+      int lb = 0;
+      for (int o = low->first_oct; o < low->g->noct; o++) lb += low->nlv * (((low->g->o[o].wa >> 2) * low->g->o[o].h + 255) >> 8);
+      if (lb > 0) { m.low_blocks = lb; blocks += lb * batch; }
+    }
     switch (r) {
-      case 8: launch_multi_r<8>(st, m, blocks); break;
-      case 9: launch_multi_r<9>(st, m, blocks); break;
-      case 10: launch_multi_r<10>(st, m, blocks); break;
-      case 11: launch_multi_r<11>(st, m, blocks); break;
-      default: launch_multi_r<12>(st, m, blocks); break;
+      case 8: launch_multi_r<8>(st, m, mg, blocks); break;
+      case 9: launch_multi_r<9>(st, m, mg, blocks); break;
+      case 10: launch_multi_r<10>(st, m, mg, blocks); break;
+      case 11: launch_multi_r<11>(st, m, mg, blocks); break;
+      default: launch_multi_r<12>(st, m, mg, blocks); break;
     }
   }
   return true;
