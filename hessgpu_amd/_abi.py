@@ -7,7 +7,7 @@ CPU oracle's `hess_cpu_` entry points with the same table so both sides read ali
 """
 import ctypes as C
 
-HESS_ABI_VERSION = 2
+HESS_ABI_VERSION = 3
 
 HESS_OK = 0
 HESS_ERR_ARG = -1
@@ -19,6 +19,7 @@ HESS_ERR_UNSUPPORTED = -6
 
 TYPE_DARK_BLOB, TYPE_BRIGHT_BLOB, TYPE_SADDLE, TYPE_NONE = 0, 1, 2, 3
 TRUNC_HIGHEST_0, TRUNC_HIGHEST_1, TRUNC_LOWEST, TRUNC_TOPK = 0, 1, 2, 3
+DESC_ORDER_INTERLEAVED, DESC_ORDER_SEQUENTIAL = 0, 1
 FMT_LUM, FMT_LUM_ALPHA, FMT_RGB, FMT_RGBA, FMT_BGR, FMT_BGRA = 1, 2, 3, 4, 5, 6
 PIX_U8, PIX_U16, PIX_F32 = 1, 2, 3
 DBG_GAUSS, DBG_DETH, DBG_GOT = 0, 1, 2
@@ -57,7 +58,8 @@ class HessParams(C.Structure):
         ("auto_downscale", C.c_int32),
         ("verbose", C.c_int32),
         ("dynamic_indexing", C.c_int32),
-        ("reserved", C.c_int32 * 7),   # must be zero for the product (word 0: the test oracle's detector switch)
+        ("descriptor_order", C.c_int32),   # DESC_ORDER_*
+        ("reserved", C.c_int32 * 6),   # must be zero for the product (word 0: the test oracle's detector switch)
     ]
 
 

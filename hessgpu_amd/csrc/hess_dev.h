@@ -134,6 +134,8 @@ struct DescParams {
   HostKeypoint* hkeys;   // optional pinned-host mirrors of the packed results (same indexing as keys/desc)
   float* hdesc;
   int first_image;       // the launch covers images first_image .. first_image + gridDim.y - 1 of the batch
+  int xcd_block;         // features per block of the list handed to one XCD's workgroups (0: plain order)
+  int sequential;        // HESS_DESC_ORDER_SEQUENTIAL: bins summed in the reference's sample order (else four interleaved partial sums)
 };
 
 // ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------

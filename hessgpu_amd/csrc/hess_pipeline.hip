@@ -195,6 +195,7 @@ struct hess_ctx {
   int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
   bool no_host_upload = false;     // HESS_NO_SIDE_UPLOAD: pinned input is uploaded by a copy on the context's stream (A/B switch)
   int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
+  int desc_xcd_block = 64;         // HESS_DESC_XCD: features per XCD block of the descriptor launch (0: plain order; A/B switch)
   Copier cp;
   Stager sg;
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
@@ -880,6 +881,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
   dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   dsp.first_image = 0;
+  dsp.xcd_block = c->desc_xcd_block;
+  dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   // Delivered by the copier thread, a batch of four or more images gets its descriptors in two launches (the images
   // are independent and packed back to back): the first half's results cross the host link while the second half is
   // computed -- half of the transfer (0.53 ms for eight 1080p images) leaves the batch's critical path.  Four groups
@@ -1016,6 +1019,8 @@ int enqueue_user(hess_ctx* c) {
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
   dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   dsp.first_image = 0;
+  dsp.xcd_block = c->desc_xcd_block;
+  dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   c->nparts = 1;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
@@ -1476,8 +1481,9 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (params) c->p = *params; else default_params(&c->p);
   bool reserved_nonzero = false;
   for (int r : c->p.reserved) reserved_nonzero = reserved_nonzero || r != 0;
+  if (c->p.abi_version == 2 && c->p.descriptor_order == 0) c->p.abi_version = HESS_ABI_VERSION;  // a version-2 struct: same layout, the new word zero
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
-      reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
+      c->p.descriptor_order < 0 || c->p.descriptor_order > HESS_DESC_ORDER_SEQUENTIAL || reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;
@@ -1514,6 +1520,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
+  if (const char* dx = getenv("HESS_DESC_XCD")) c->desc_xcd_block = atoi(dx) > 0 ? atoi(dx) : 0;
   return c;
 }
 

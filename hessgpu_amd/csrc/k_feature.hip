@@ -479,7 +479,7 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
 // HOST_MIRROR: the packed results are also stored into their pinned host mirrors (dp.hkeys / dp.hdesc); a template
 // parameter so that the two forms carry different names in profiles (alone on the device the mirroring form waits
 // for PCIe).
-template <bool HOST_MIRROR>
+template <bool HOST_MIRROR, bool SEQ>
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, const RawKey* list,
                                                          int cap_list, const FRec* recs,
                                                          const int* fsrc, const int* feat_total,
@@ -550,7 +550,16 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   // Features are taken from the END of the list backwards: the list is ordered by (octave, level), most features
   // belong to octave 0, and within an octave the footprint grows with the level, so the launch's last wavefronts --
   // its tail -- get the smallest features (octave 0, level 1) instead of a mixture.
-  for (int mw = blockIdx.x * 4 + wv; mw < ftotal; mw += nwaves) {
+  // ... and in blocks of 64 consecutive features per XCD: workgroups are dealt round-robin over the eight XCDs, each with
+  // its own L2, while features that are neighbours in the list are neighbours in the image (raster order within a
+  // level) and read overlapping footprints -- so a block of the list goes to the workgroups of ONE XCD instead of
+  // being spread over all eight L2s (dp.xcd_block: 64, or 0 for the plain order when the grid does not divide).
+  int mw0 = blockIdx.x * 4 + wv;
+  if (dp.xcd_block) {
+    const int xcd = blockIdx.x & 7, wx = (int)(blockIdx.x >> 3) * 4 + wv;  // wavefront index inside the XCD
+    mw0 = ((wx / dp.xcd_block) * 8 + xcd) * dp.xcd_block + wx % dp.xcd_block;
+  }
+  for (int mw = mw0; mw < ftotal; mw += nwaves) {
     const int m = ffirst + ftotal - 1 - mw;
     const int src = fsrc[(long long)b * cap_feat + m];
     const int i = src >> 2, k = src & 3;
@@ -681,6 +690,17 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         const float fo = floorf(theta);
         const float w1 = fo + 1.0f - theta, w2 = theta - fo;  // ProgramCU.cu:1752-1753
         const int fidx = min(max((int)fo, 0), DC_BINS - 2);  // 0..8 for every finite theta; never outside the table
+        if (!SEQ) {
+          // HESS_DESC_ORDER_INTERLEAVED: the lane adds its own sample into its own 12-bin histogram in LDS
+          // ([bin][lane]: conflict-free); the four lanes of a cell are summed in a fixed order after the scan.  No
+          // coefficient table, no quad broadcasts: 57 instead of 71 vector instructions per iteration.  A sample
+          // that is not `hit` has weight 0 and leaves both sums as they are.
+          float* const hp = rows + fidx * 64 + lane;
+          const float a = hp[0], b2 = hp[64];
+          hp[0] = fmaf(w1, wt, a);
+          hp[64] = fmaf(w2, wt, b2);
+          return;
+        }
         mycol[fidx * DC_BIN_PITCH] = w1;
         mycol[fidx * DC_BIN_PITCH + DC_BIN_PITCH] = w2;
         __builtin_amdgcn_wave_barrier();  // cross-lane through LDS inside the wavefront: pins the compiler's order only
@@ -720,6 +740,22 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
         stage_a(std::false_type{}, it0 + 2 * UN, ca);
         stage_b(cb);
       }
+    }
+    if (!SEQ) {  // des[bin] = (p0 + p1) + (p2 + p3) over the cell's four lanes; then the histograms are cleared again
+      __builtin_amdgcn_wave_barrier();
+      const float* const hb = rows + mycell * 4;
+      const float4 h0 = *reinterpret_cast<const float4*>(hb + sub * 64);
+      const float4 h1 = *reinterpret_cast<const float4*>(hb + (sub + 4) * 64);
+      const float4 h2 = *reinterpret_cast<const float4*>(hb + (sub + 8) * 64);
+      acc0 = (h0.x + h0.y) + (h0.z + h0.w);
+      acc1 = (h1.x + h1.y) + (h1.z + h1.w);
+      acc2 = (h2.x + h2.y) + (h2.z + h2.w);
+      __builtin_amdgcn_wave_barrier();
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(rows + mycell * 4 + sub * 64) = z4;
+      *reinterpret_cast<float4*>(rows + mycell * 4 + (sub + 4) * 64) = z4;
+      *reinterpret_cast<float4*>(rows + mycell * 4 + (sub + 8) * 64) = z4;
+      __builtin_amdgcn_wave_barrier();
     }
     if (sub == 0) acc0 += acc2;  // des[0] += des[8], ProgramCU.cu:1776
     if (dp.half_sift) {
@@ -801,12 +837,15 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const int lds_pad = DC_LDS_PAD_BYTES;
-  if (dp.hkeys || dp.hdesc)
-    hipLaunchKernelGGL(descriptor_kernel<true>, dim3(blocks, batch), dim3(256), lds_pad, st, g, dp, list, cap_list, recs, fsrc,
-                       feat_total, feat_first, img_base, got, keys, desc, cap_feat);
-  else
-    hipLaunchKernelGGL(descriptor_kernel<false>, dim3(blocks, batch), dim3(256), lds_pad, st, g, dp, list, cap_list, recs, fsrc,
-                       feat_total, feat_first, img_base, got, keys, desc, cap_feat);
+  DescParams dpx = dp;
+  if (dpx.xcd_block && (blocks * 4) % (8 * dpx.xcd_block) != 0) dpx.xcd_block = 0;  // the block order needs whole blocks per XCD
+#define HESS_DESC_LAUNCH(MIRROR, SEQ)                                                                                  \
+  hipLaunchKernelGGL((descriptor_kernel<MIRROR, SEQ>), dim3(blocks, batch), dim3(256), lds_pad, st, g, dpx, list, cap_list, \
+                     recs, fsrc, feat_total, feat_first, img_base, got, keys, desc, cap_feat)
+  const bool mirror = dp.hkeys || dp.hdesc;
+  if (dp.sequential) { if (mirror) HESS_DESC_LAUNCH(true, true); else HESS_DESC_LAUNCH(false, true); }
+  else { if (mirror) HESS_DESC_LAUNCH(true, false); else HESS_DESC_LAUNCH(false, false); }
+#undef HESS_DESC_LAUNCH
 }
 
 }  // namespace hess

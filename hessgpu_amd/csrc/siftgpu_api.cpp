@@ -268,7 +268,11 @@ void SiftGPU::PrintUsage() {
                "-f <f> -w <f> -dw <f>                    filter width, orientation window, descriptor window factors\n"
                "-m [n] -s [n] -ofix -ofix-not -loweo     orientations, sub-pixel, fixed orientation, Lowe origin\n"
                "-topk <n> -tc/-tc1/-tc2/-tc3 <n>         limit the number of features\n"
-               "-half -sd -b -bvlf -ads -maxd <n> -p WxH -tight -cuda <dev> -v <0..4>\n";
+               "-half -sd -b -bvlf -ads -maxd <n> -p WxH -tight -cuda <dev> -v <0..4>\n"
+               "-dseq                                    descriptor bins summed in the reference's sequential order\n"
+               "                                         (default: four interleaved partial sums, 16 % faster, equal within 1e-6)\n"
+               "Image files: PGM / PPM (P2 P3 P5 P6) only -- this build has no DevIL; convert JPEG / PNG first, or hand\n"
+               "the decoded pixels to RunSIFT(width, height, data, gl_format, gl_type).\n";
 }
 
 void SiftGPU::SetVerbose(int verbose) {  // SiftGPU.cpp:433-464
@@ -313,6 +317,7 @@ void SiftGPU::ParseParam(int argc, char** argv) {  // SiftGPU.cpp:855-1380
         k == "k0" || k == "kx" || k == "da" || k == "fmc" || k == "nomc")
       continue;  // accepted, no effect on this backend
     if (k == "di") { p.dynamic_indexing = 1; continue; }  // SiftGPU.cpp:1030-1032
+    if (k == "dseq") { p.descriptor_order = HESS_DESC_ORDER_SEQUENTIAL; continue; }  // this build only: hess_abi.h
     if (k == "sd") { if (!_initialized) p.compute_descriptors = 0; continue; }
     if (k == "b") { im->binary_sift = 1; continue; }
     if (k == "ads") { p.auto_downscale = 1; continue; }

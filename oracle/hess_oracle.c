@@ -754,8 +754,18 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
     float ymax = border_hi(c, pty + bsz, height);
     float des[9];
     for (int i = 0; i < 9; ++i) des[i] = 0.0f;
+    /* HESS_DESC_ORDER_INTERLEAVED (include/hess_abi.h; NOT the reference's order, which is the sequential one below):
+     * the samples at positions 0, 1, 2, 3 modulo 4 of the scan over the cell's box are summed apart (part[]) and the
+     * four sums added as (p0 + p1) + (p2 + p3) -- the product's default summation order, restated here so that the
+     * comparison with the HIP path stays bitwise in that mode too.  tests/test_descriptor_order.py bounds the
+     * difference between the two orders. */
+    const int interleaved = c->p.descriptor_order == HESS_DESC_ORDER_INTERLEAVED;
+    float part[4][9];
+    for (int q = 0; q < 4; ++q) for (int i = 0; i < 9; ++i) part[q][i] = 0.0f;
+    unsigned t = 0; /* position in the scan of the box, outside-the-window samples included */
     for (float y = ymin; y <= ymax; y += 1.0f) {
-      for (float x = xmin; x <= xmax; x += 1.0f) {
+      for (float x = xmin; x <= xmax; x += 1.0f, ++t) {
+        float* const acc = interleaved ? part[t & 3u] : des;
         float dx = x - ptx;
         float dy = y - pty;
         float nx = fmaf(crspt, dx, srspt * dy);
@@ -776,16 +786,18 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
           float weight1 = fo + 1.0f - theta;
           float weight2 = theta - fo;
           if (fidx >= 0 && fidx < 8) { /* DYNAMIC_INDEXING = false: k==fidx for k<8 only (:1763-1771) */
-            des[fidx] = fmaf(weight1, weight, des[fidx]);
-            des[fidx + 1] = fmaf(weight2, weight, des[fidx + 1]);
+            acc[fidx] = fmaf(weight1, weight, acc[fidx]);
+            acc[fidx + 1] = fmaf(weight2, weight, acc[fidx + 1]);
           } else if (fidx == 8 && c->p.dynamic_indexing) {
             /* -di, DYNAMIC_INDEXING = true (:1755-1759): des[8] += weight1*weight; the reference also
              * writes des[9] (one past the array) += weight2*weight = +0: not restated */
-            des[8] = fmaf(weight1, weight, des[8]);
+            acc[8] = fmaf(weight1, weight, acc[8]);
           }
         }
       }
     }
+    if (interleaved)
+      for (int i = 0; i < 9; ++i) des[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     des[0] += des[8];
     if (half) {
       des[0] += des[4]; des[1] += des[5]; des[2] += des[6]; des[3] += des[7];

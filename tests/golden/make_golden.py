@@ -42,7 +42,7 @@ def digest(name, kw):
         img = fixtures.synthetic_blobs(w, h, int(idx))
     else:
         img = fixtures.load_rgb(name)
-    o = OracleSession(threads=4, keep_levels=False, **kw)
+    o = OracleSession(threads=4, keep_levels=False, descriptor_order=1, **kw)  # the reference's (sequential) summation order
     n = o.run(img[None])[0]
     k, d = o.fetch(0)
     raw = o.rawlist(0)

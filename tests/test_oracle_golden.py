@@ -25,7 +25,9 @@ def test_oracle_matches_golden(case):
         img = fixtures.load_rgb(name)
     if hashlib.sha256(img.tobytes()).hexdigest() != case["input_sha256"]:
         pytest.skip("image decoder produced different pixels than when the golden was made")
-    o = OracleSession(threads=2, keep_levels=False, **case["params"])
+    # the digests pin the oracle in the REFERENCE's descriptor summation order (sequential); the interleaved order of
+    # hess_abi.h (the product's default, restated by the oracle as well) is tied to it by tests/test_descriptor_order.py
+    o = OracleSession(threads=2, keep_levels=False, descriptor_order=1, **case["params"])
     n = o.run(img[None])[0]
     k, d = o.fetch(0)
     assert n == case["features"] and len(o.rawlist(0)) == case["locations"]

@@ -37,12 +37,13 @@ def _assert_pinned(r, vals):
     assert (r["err"][~it] <= 1).mean() > 0.3                                        # border keypoints: reported only
 
 
-def test_oracle_orientation_and_descriptors_match_the_reference_file():
+@pytest.mark.parametrize("order", [0, 1], ids=["interleaved", "sequential"])  # hess_params.descriptor_order: both pinned by the file
+def test_oracle_orientation_and_descriptors_match_the_reference_file(order):
     img, vals = bf.load()
     assert img.shape == (bf.H, bf.W) and vals.shape == (673, 132)
     ref = vals[:, 4:] / 512.0
     assert np.all(np.abs(np.linalg.norm(ref, axis=1) - 1.0) < 0.02)      # unit descriptors, quantised
-    o = OracleSession(threads=8, **bf.PARAMS)
+    o = OracleSession(threads=8, descriptor_order=order, **bf.PARAMS)
     r = bf.analyse(o, img, vals)
     _assert_pinned(r, vals)
     # controls: the same keypoints with the angle sense flipped / the origin moved by a pixel agree nowhere
