@@ -175,10 +175,51 @@ def main():
             ctxs = make_contexts()
     for c in ctxs:
         c.reserve(W, H, B)
+    placement = None
     if gather_dest == "shm":
-        if rank == 0:   # (the all_reduce above is the barrier: every rank's directories exist)
-            readers = {r: [hdist.SharedResultsReader(f"{shm_prefix}_{tok[0]}_r{r}_c{j}") for j in range(nctx)]
-                       for r in range(1, world)}
+        # The shared result buffers are sized by need (the first batch + 25 %), so they are allocated by the first batch of
+        # every context: run it here, locally (no collective inside), and let every rank take the same decision.  Where
+        # /dev/shm has no room the library puts a buffer into a file under HESS_SHARE_DIR / TMPDIR instead (mapped and
+        # registered the same way); only when that fails too do all ranks fall back to the landing through rank 0's link.
+        ok = 1
+        try:
+            for c in ctxs:
+                c.run_device(d_imgs.data_ptr(), B, H, W)
+        except Exception as e:
+            print(f"bench.py: rank {rank}: node-shared result buffers unavailable ({e})", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            gather_dest = "host"
+            for c in ctxs:
+                c.close()
+            ctxs = make_contexts()
+            for c in ctxs:
+                c.reserve(W, H, B)
+        else:
+            mine = [hdist.SharedResultsReader(f"{shm_prefix}_{tok[0]}_r{rank}_c{j}").placement() for j in range(nctx)]
+            allp = [None] * world
+            tdist.all_gather_object(allp, mine, group=hdist.count_group())
+            placement = allp
+            if rank == 0:
+                readers = {r: [hdist.SharedResultsReader(f"{shm_prefix}_{tok[0]}_r{r}_c{j}") for j in range(nctx)]
+                           for r in range(1, world)}
+                try:
+                    st = os.statvfs("/dev/shm")
+                    free_mb = st.f_bavail * st.f_frsize / 1e6
+                except OSError:
+                    free_mb = float("nan")
+                tot = sum(p["bytes"] for ps in allp for p in ps)
+                in_files = sum(p["bytes"] for ps in allp for p in ps if not p["desc"].startswith("/dev/shm/"))
+                print(f"bench.py: node-shared result buffers: {tot / 1e6:.0f} MB for {world} rank(s) x {nctx} contexts "
+                      f"({tot / 1e6 / max(1, world * nctx):.1f} MB each, sized by need); /dev/shm has {free_mb:.0f} MB free now; "
+                      f"{in_files / 1e6:.0f} MB of them in files instead (no room in /dev/shm)", file=sys.stderr)
+                for r, ps in enumerate(allp):
+                    where = sorted({os.path.dirname(p["desc"]) for p in ps})
+                    print(f"bench.py:   rank {r}: {sum(p['bytes'] for p in ps) / 1e6:.0f} MB in {', '.join(where)}", file=sys.stderr)
+    if use_dist and rank == 0 and gather_dest != "shm":
+        print(f"bench.py: gather destination of every rank: {gather_dest}", file=sys.stderr)
     landing = hdist.HostLanding() if gather_dest == "host" else None
     gathered = {}
 
@@ -335,6 +376,10 @@ def main():
                              if use_dist else "single GPU"),
                 "input": "u8 luminance resident in HBM; results delivered to host memory",
                 **({"gather_dest": gather_dest} if use_dist else {}),
+                **({"shared_result_buffers_mb": round(sum(p["bytes"] for ps in placement for p in ps) / 1e6, 1),
+                    "shared_result_buffers_in_files_mb": round(sum(p["bytes"] for ps in placement for p in ps
+                                                                   if not p["desc"].startswith("/dev/shm/")) / 1e6, 1)}
+                   if placement else {}),
                 "result_delivery": "copier thread: DMA copy of the exact byte count, no dependency on a kernel "
                                    "(batches of 1-2 images: stores of the descriptor kernel into pinned memory)",
             },

@@ -52,7 +52,8 @@ struct Schedule {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
-  std::string shm;  // non-empty: p is a registered mapping of this POSIX shared memory object (hess_share_results)
+  std::string shm;  // non-empty: p is a registered mapping of this POSIX shared memory object ("/name") or, when /dev/shm
+                    // had no room, of this file (an absolute path: it has further slashes) -- hess_share_results
 };
 
 struct EventPair {
@@ -178,7 +179,14 @@ struct hess_ctx {
   // hess_share_results: the two result buffers live in shared memory objects "/<share>.k<n>" / "/<share>.d<n>" that
   // another process of the node can map; a 4 KB directory object "/<share>.h" says which ones are current
   std::string share;
-  struct ShareDir { uint32_t magic, gen_keys, gen_desc, pad; uint64_t keys_bytes, desc_bytes; }* share_dir = nullptr;
+  // (directory layout = hessgpu_amd/dist.py SharedResultsReader._HDR: generations, sizes and the absolute paths of the
+  // current buffers -- under /dev/shm, or under HESS_SHARE_DIR / TMPDIR when /dev/shm has no room for them)
+  struct ShareDir {
+    uint32_t magic, gen_keys, gen_desc, pad;
+    uint64_t keys_bytes, desc_bytes;
+    char keys_path[1024], desc_path[1024];
+  }* share_dir = nullptr;
+  bool share_by_need = false;      // the shared result buffers are sized by the batches seen, not for the worst case
   DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
   size_t last_input_bytes = 0;     // bytes of the last batch handed over by hess_submit_host (still in `stage`)
   hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
@@ -195,6 +203,7 @@ struct hess_ctx {
   int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
   bool no_host_upload = false;     // HESS_NO_SIDE_UPLOAD: pinned input is uploaded by a copy on the context's stream (A/B switch)
   int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
+  int stream_rows = 0;             // HESS_STREAM_ROWS: rows per wavefront segment of the extrema scan (0: by batch size; A/B switch)
   int desc_xcd_block = 64;         // HESS_DESC_XCD: features per XCD block of the descriptor launch (0: plain order; A/B switch)
   Copier cp;
   Stager sg;
@@ -267,7 +276,8 @@ void release(DevBuf& b, bool pinned_host = false) {
   if (b.p && !b.shm.empty()) {
     (void)hipHostUnregister(b.p);
     (void)munmap(b.p, b.bytes);
-    (void)shm_unlink(b.shm.c_str());
+    if (strchr(b.shm.c_str() + 1, '/')) (void)unlink(b.shm.c_str());  // a file (the fallback), else a shared memory object
+    else (void)shm_unlink(b.shm.c_str());
     b.shm.clear();
   } else if (b.p) {
     if (pinned_host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
@@ -280,51 +290,79 @@ void release(DevBuf& b, bool pinned_host = false) {
 // a POSIX shared memory object, mapped and registered with the runtime, so that the copier's DMA copy (or the
 // descriptor kernel's own stores) lands in memory the consumer process has mapped as well -- every GPU of a node
 // delivers over its own host link and nothing is funnelled through one rank's.  `which` is 'k' or 'd'.
+// Where /dev/shm has no room (containers often give it 64 MB) the buffer becomes a file under HESS_SHARE_DIR / TMPDIR /
+// /tmp instead, mapped MAP_SHARED and registered the same way: page-cache pages, pinned by the registration -- the
+// consumer maps the same pages.  Slower to set up, the same to use.  HESS_SHARE_FORCE_FILE=1 skips /dev/shm (tests).
 int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which) {
   if (bytes <= b.bytes) return 0;
   const long page = sysconf(_SC_PAGESIZE);
-  size_t want = bytes + bytes / 8;
+  size_t want = bytes + bytes / 4;  // grown by need: a quarter of slack so that batches of similar size do not reallocate
   want = (want + (size_t)page - 1) / (size_t)page * (size_t)page;
   uint32_t& gen = which == 'k' ? c->share_dir->gen_keys : c->share_dir->gen_desc;
-  char name[256];
+  char name[256], path[1024];
   snprintf(name, sizeof(name), "/%s.%c%u", c->share.c_str(), which, gen + 1);
-  (void)shm_unlink(name);  // a stale object of a dead job with the same name
-  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-  if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", name, strerror(errno)); return HESS_ERR_NOMEM; }
-  // (posix_fallocate, not ftruncate: a full /dev/shm must fail here, not as a bus error at the first store)
-  int fe = posix_fallocate(fd, 0, (off_t)want);
-  if (fe == EOPNOTSUPP || fe == EINVAL) fe = ftruncate(fd, (off_t)want) == 0 ? 0 : errno;
-  if (fe != 0) {
-    set_err(c, "cannot size the shared result buffer %s to %zu bytes: %s", name, want, strerror(fe));
-    close(fd); shm_unlink(name);
-    return HESS_ERR_NOMEM;
+  // (posix_fallocate, not ftruncate: a full file system must fail here, not as a bus error at the first store)
+  auto size_fd = [&](int fd) {
+    int fe = posix_fallocate(fd, 0, (off_t)want);
+    if (fe == EOPNOTSUPP || fe == EINVAL) fe = ftruncate(fd, (off_t)want) == 0 ? 0 : errno;
+    return fe;
+  };
+  int fd = -1, why = 0;
+  bool is_file = false;
+  if (!getenv("HESS_SHARE_FORCE_FILE")) {
+    (void)shm_unlink(name);  // a stale object of a dead job with the same name
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) why = errno;
+    else if ((why = size_fd(fd)) != 0) { close(fd); shm_unlink(name); fd = -1; }
+    if (fd >= 0) snprintf(path, sizeof(path), "/dev/shm%s", name);
+  } else {
+    why = ENOSPC;
   }
+  if (fd < 0) {  // the fallback: a file
+    const char* dir = getenv("HESS_SHARE_DIR");
+    if (!dir || !dir[0]) dir = getenv("TMPDIR");
+    if (!dir || !dir[0]) dir = "/tmp";
+    snprintf(path, sizeof(path), "%s%s", dir, name);
+    (void)unlink(path);
+    fd = open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+    int fe = fd < 0 ? errno : size_fd(fd);
+    if (fe != 0) {
+      if (fd >= 0) { close(fd); unlink(path); }
+      set_err(c, "cannot place the shared result buffer %s (%zu bytes): /dev/shm: %s; %s: %s", name + 1, want, strerror(why), path, strerror(fe));
+      return HESS_ERR_NOMEM;
+    }
+    is_file = true;
+  }
+  auto drop = [&]() { if (is_file) unlink(path); else shm_unlink(name); };
   void* np = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
   close(fd);
-  if (np == MAP_FAILED) { set_err(c, "mmap(%s) failed: %s", name, strerror(errno)); shm_unlink(name); return HESS_ERR_NOMEM; }
+  if (np == MAP_FAILED) { set_err(c, "mmap(%s) failed: %s", path, strerror(errno)); drop(); return HESS_ERR_NOMEM; }
   void* dp = nullptr;
   hipError_t e = hipHostRegister(np, want, hipHostRegisterPortable | hipHostRegisterMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, np, 0);
   if (e != hipSuccess || dp != np) {  // (the kernels and the copier address the buffer by its host pointer)
     if (e == hipSuccess) (void)hipHostUnregister(np);
     else (void)hipGetLastError();
-    set_err(c, "cannot register the shared result buffer %s with the runtime: %s", name,
+    set_err(c, "cannot register the shared result buffer %s with the runtime: %s", path,
             e != hipSuccess ? hipGetErrorString(e) : "device alias differs from the host address");
-    munmap(np, want); shm_unlink(name);
+    munmap(np, want); drop();
     return e == hipErrorOutOfMemory ? HESS_ERR_NOMEM : HESS_ERR_DEVICE;
   }
   release(b, true);
   try {
-    b.shm = name;
+    b.shm = is_file ? path : name;
   } catch (...) {  // (nothing thrown crosses the C ABI)
     (void)hipHostUnregister(np);
-    munmap(np, want); shm_unlink(name);
+    munmap(np, want); drop();
     set_err(c, "out of memory");
     return HESS_ERR_NOMEM;
   }
   b.p = np; b.bytes = want;
-  gen++;
+  // size and path first, the generation number last: a reader that sees the new generation sees its buffer
   (which == 'k' ? c->share_dir->keys_bytes : c->share_dir->desc_bytes) = want;
+  snprintf(which == 'k' ? c->share_dir->keys_path : c->share_dir->desc_path, sizeof(c->share_dir->keys_path), "%s", path);
+  __sync_synchronize();
+  gen++;
   __sync_synchronize();
   return 0;
 }
@@ -541,7 +579,11 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
     // The pinned result buffers hold the worst case B * cap_feat records up front while that stays moderate; beyond
     // it they grow on demand once the counts are known (wait_impl / the copier), and the in-kernel mirror is not used.
     const size_t host_bytes = (size_t)B * cap_feat * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
-    c->host_fits = host_bytes <= ((size_t)512 << 20);
+    // Node-shared result buffers of a batch the copier delivers are sized by the batches seen (+ 25 %), not for the
+    // worst case B * cap_feat: six contexts x eight ranks x 79 MB of worst case were 3.8 GB of /dev/shm for 1.2 GB of
+    // results; the copier (or hess_wait) grows them under a new generation when a batch needs more.
+    c->share_by_need = c->share_dir && B > c->mirror_max_batch && c->delivery_pref != kDeliverMirror;
+    c->host_fits = !c->share_by_need && host_bytes <= ((size_t)512 << 20);
     if (c->host_fits) {
       if ((rc = ensure(c, c->h_keys, (size_t)B * cap_feat * sizeof(HostKeypoint), true))) return rc;
       if (c->dim && (rc = ensure(c, c->h_desc, (size_t)B * cap_feat * c->dim * 4, true))) return rc;
@@ -820,7 +862,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     for (int o = 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
     Geom gx = g;
-    if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);  // one or two images: shorter segments, twice the wavefronts
+    if (c->stream_rows > 0) set_stream_rows(gx, c->stream_rows);      // HESS_STREAM_ROWS (A/B switch; a multiple of 3)
+    else if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);        // one or two images: shorter segments, twice the wavefronts
     launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
@@ -1520,6 +1563,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
+  if (const char* sr = getenv("HESS_STREAM_ROWS")) c->stream_rows = atoi(sr) > 0 ? (atoi(sr) / 3) * 3 : 0;
   if (const char* dx = getenv("HESS_DESC_XCD")) c->desc_xcd_block = atoi(dx) > 0 ? atoi(dx) : 0;
   return c;
 }

@@ -525,24 +525,30 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
           // more than one per row, so this is one trip, not one per level and column; the order inside the queue
           // does not matter -- accepted pixels set positional mask bits)
           for (uint64_t m = __builtin_amdgcn_ballot_w64(cand != 0); m != 0; m = __builtin_amdgcn_ballot_w64(cand != 0)) {
+            // (cross-lane exchange through LDS inside one wavefront: DS operations of a wavefront execute in order; the
+            // wave barriers only pin the compiler's ordering of the may-alias accesses, they emit no instruction)
             if (cand != 0) {
               const int k = __builtin_ctz(cand);
               q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
                   ((uint32_t)(k / NC + 1) << 28) | ((uint32_t)y << 14) | (uint32_t)(cx + k % NC);
               cand &= cand - 1;
             }
+            __builtin_amdgcn_wave_barrier();
             qn += __popcll(m);
             if (qn >= 64) {
-              process(q[lane], true);
-              const uint32_t tail = q[64 + lane];
+              const uint32_t head = q[lane], tail = q[64 + lane];
+              __builtin_amdgcn_wave_barrier();
+              process(head, true);
               qn -= 64;
               if (lane < qn) q[lane] = tail;
+              __builtin_amdgcn_wave_barrier();
             }
           }
         }
       }
     }
   }
+  __builtin_amdgcn_wave_barrier();
   if (qn > 0) process(q[lane < qn ? lane : 0], lane < qn);
 }
 

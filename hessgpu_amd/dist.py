@@ -226,7 +226,7 @@ class SharedResultsReader:
     context's next batch."""
 
     _HDR = np.dtype([("magic", "<u4"), ("gen_keys", "<u4"), ("gen_desc", "<u4"), ("pad", "<u4"),
-                     ("keys_bytes", "<u8"), ("desc_bytes", "<u8")])
+                     ("keys_bytes", "<u8"), ("desc_bytes", "<u8"), ("keys_path", "S1024"), ("desc_path", "S1024")])
 
     def __init__(self, name, shm_dir="/dev/shm"):
         import mmap
@@ -246,15 +246,24 @@ class SharedResultsReader:
     def _buffer(self, which, gen):
         have, m = self._maps[which]
         if have != gen:
-            if m is not None:
-                m.close()
-            fd = self._os.open(self._os.path.join(self._dir, f"{self._name}.{which}{gen}"), self._os.O_RDONLY)
+            # (the old mapping is dropped, not closed: views of an earlier batch may still be alive and keep it mapped;
+            # the producer publishes size and path before the generation number, so a new generation has its path)
+            path = bytes(self._hdr["keys_path" if which == "k" else "desc_path"][0]).split(b"\0")[0].decode()
+            if not path:   # a directory written without paths: the object's name under the shm directory
+                path = self._os.path.join(self._dir, f"{self._name}.{which}{gen}")
+            fd = self._os.open(path, self._os.O_RDONLY)
             try:
                 m = self._mmap.mmap(fd, 0, prot=self._mmap.PROT_READ)
             finally:
                 self._os.close(fd)
             self._maps[which] = (gen, m)
         return m
+
+    def placement(self):
+        """-> {"keys": path, "desc": path, "bytes": total}: where the producer's current buffers live."""
+        h = self._hdr
+        return {"keys": bytes(h["keys_path"][0]).split(b"\0")[0].decode(), "desc": bytes(h["desc_path"][0]).split(b"\0")[0].decode(),
+                "bytes": int(h["keys_bytes"][0]) + int(h["desc_bytes"][0])}
 
     def views(self, total, dim):
         """-> (keys uint8 [total, 24], desc float32 [total, dim] or None): read-only numpy views of the first `total`

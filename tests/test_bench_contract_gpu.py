@@ -75,22 +75,42 @@ def test_bench_json_line():
     assert r4["bound"] == "hbm" and r4["peak"] == 8000.0 and 0 < r4["frac"] < 1 and r4["features_per_launch"] == c4["features"]
 
 
-def test_two_rank_control_flow_on_one_gpu():
+@pytest.mark.parametrize("dest", ["shm", "file", "host"])
+def test_two_rank_control_flow_on_one_gpu(dest, tmp_path):
     """The N > 1 path of bench.py rehearsed with two ranks that share the one GPU (gloo instead of RCCL, which cannot
-    form a group of ranks on the same device): count exchange, gather, rank 0 reading rank 1's lists in place from
-    the node-shared result buffers, and image 0 of BOTH ranks compared with the oracle out of those buffers."""
+    form a group of ranks on the same device): count exchange, gather, and image 0 of BOTH ranks compared with the
+    oracle out of what rank 0 holds at the end of a step -- for each of the three places the other rank's lists can
+    reach rank 0's host memory through:
+      shm   rank 0 reads them in place from the node-shared result buffers in /dev/shm (sized by need);
+      file  the same with the buffers in files (what the library does when /dev/shm has no room: forced here);
+      host  no shared buffers at all (a name the library refuses): rank 0 copies the gathered lists out of its HBM."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HESS_BENCH_BACKEND="gloo", HESS_BENCH_SAME_GPU="1")
+    if dest == "file":
+        env.update(HESS_SHARE_FORCE_FILE="1", HESS_SHARE_DIR=str(tmp_path))
+    if dest == "host":
+        env["HESS_BENCH_SHM_PREFIX"] = "no/such"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "2", "--no-profile"],
+                        "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "3", "--no-profile"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather_dest"] == "shm"
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["gather_dest"] == ("host" if dest == "host" else "shm")
     assert d["parity_checked"] is True and d["parity_checked_ranks"] == 2
-    assert abs(d["value"] - 2 * 2 * 4 * 1920 * 1080 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.01
+    assert abs(d["value"] - 2 * 3 * 4 * 1920 * 1080 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.01
+    if dest != "host":
+        mb, in_files = d["config"]["shared_result_buffers_mb"], d["config"]["shared_result_buffers_in_files_mb"]
+        # sized by need: 2 ranks x 2 contexts x 3 images x ~5.6 k features x 536 B + 25 % -- far below the worst case
+        # (3 x 16384 records per context: 105 MB for the four)
+        assert 30 < mb < 70, mb
+        assert (in_files == mb) if dest == "file" else (in_files == 0)
+        assert "node-shared result buffers:" in r.stderr
+    else:
+        assert "gather destination of every rank: host" in r.stderr
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("hessbench_")]
+    assert not list(tmp_path.iterdir())          # the files are gone with their contexts

@@ -112,6 +112,38 @@ def test_shared_buffers_hold_the_results_of_every_delivery_mode(gpu_ctx_factory,
 
 
 @pytest.mark.gpu
+def test_shared_buffers_are_sized_by_need_and_fall_back_to_files(gpu_ctx_factory, monkeypatch, tmp_path):
+    """A batch the copier delivers: the shared buffers hold what the batches seen need (+ 25 %), not the worst case;
+    and with no room in /dev/shm (forced) they are files under HESS_SHARE_DIR, found through the directory's paths."""
+    from hessgpu_amd.dist import SharedResultsReader
+    imgs = _imgs(4)
+    ref = gpu_ctx_factory(truncate_method=3, feature_count_threshold=300)
+    counts = ref.run(imgs)
+    ek, ed = _expect(ref, 4)
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("HESS_SHARE_FORCE_FILE", "1")
+            monkeypatch.setenv("HESS_SHARE_DIR", str(tmp_path))
+        name = f"hess_test_need_{os.getpid()}_{int(forced)}"
+        c = gpu_ctx_factory(truncate_method=3, feature_count_threshold=300)
+        c.share_results(name)
+        assert c.run(imgs) == counts
+        gk, gd, kb, db = c.shared_results_info()
+        need_k, need_d = sum(counts) * 24, sum(counts) * 128 * 4
+        assert need_k <= kb <= 1.3 * need_k + 8192 and need_d <= db <= 1.3 * need_d + 8192   # 4 x 1200 records would be the worst case
+        r = SharedResultsReader(name)
+        where = r.placement()
+        assert where["bytes"] == kb + db
+        assert os.path.dirname(where["desc"]) == (str(tmp_path) if forced else SHM) and os.path.exists(where["desc"])
+        keys, desc = r.views(sum(counts), 128)
+        assert np.array_equal(keys, ek) and np.array_equal(desc.view(np.uint32), ed.view(np.uint32))
+        del keys, desc
+        r.close()
+        c.close()
+        assert not [f for f in os.listdir(SHM) if f.startswith(name)] and not list(tmp_path.iterdir())
+
+
+@pytest.mark.gpu
 def test_share_results_argument_errors(gpu_ctx_factory):
     from hessgpu_amd.session import HessError
     c = gpu_ctx_factory()
