@@ -52,7 +52,41 @@ def test_speed_harness_reports_stable_counts(tmp_path):
     r = subprocess.run([os.path.join(BIN, "speed"), "-i", str(tmp_path / "a.pgm"), "-n", "5"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert "+++++" in r.stdout and "e" not in r.stdout.splitlines()[0] and "Hz" in r.stdout
+    # two passes as in the reference (speed.cpp:107-152): '+' per repetition without stage timers, '#' with them
+    marks = [l for l in r.stdout.splitlines() if l and set(l) <= set("+#e")]
+    assert marks == ["+++++", "#####"], r.stdout
+    vals = {l.split("]:")[0].strip("["): float(l.split("]:")[1].replace("ms per image", "").replace("ms", "").replace("hz", ""))
+            for l in r.stdout.splitlines() if l.startswith("[")}
+    o = OracleSession(threads=8, keep_levels=False)
+    o.run(lum[None])
+    assert vals["Feature Count"] == o.count(0) and vals["Average Speed"] > 0
+    for k in ("Build Pyramid", "Detection", "Feature List", "Orientation", "Descriptor"):
+        assert vals[k] > 0, (k, r.stdout)                  # stage timers were on in the second pass
+    assert vals["With stage timers"] >= 0.8 * vals["Average Time"]
+
+
+def test_multigpu_driver_gathers_on_device_0(tmp_path):
+    """apps/multigpu.cpp: one host thread per device through the C ABI, exact-size RCCL send / recv of the feature lists
+    to device 0, the gathered copy compared with every device's own host results.  On this box: every visible device
+    (one), i.e. the count table, the ncclGroup and the check without a peer."""
+    import torch
+    names = ["640-1.jpg", "640-2.jpg", "640-3.jpg"]
+    lums = [fixtures.load_rgb(n)[..., 1].copy() for n in names]
+    args = [os.path.join(BIN, "multigpu"), "-n", "3", "-batch", "3", "-topk", "500"]
+    for n, l in zip(names, lums):
+        _write_pgm(tmp_path / (n[:-4] + ".pgm"), l)
+        args += ["-i", str(tmp_path / (n[:-4] + ".pgm"))]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ndev = torch.cuda.device_count()
+    o = OracleSession(threads=8, keep_levels=False, truncate_method=3, feature_count_threshold=500)
+    want = o.run(np.stack(lums))
+    rows = [l for l in r.stdout.splitlines() if l.startswith("#")]
+    assert len(rows) == ndev
+    for d, l in enumerate(rows):          # "#d: n n n features": device d holds images 3d .. 3d+2 of the cycled list
+        assert [int(v) for v in l.split(":")[1].split()[:-1]] == [want[(3 * d + b) % 3] for b in range(3)]
+    last = r.stdout.splitlines()[-1]
+    assert last.startswith("GATHER OK") and int(last.split()[2]) == ndev * sum(want)
 
 
 def test_multithread_driver_one_instance_per_thread_per_device(tmp_path):
