@@ -19,6 +19,7 @@
 //   topk           15-bit histogram of abs(half(response)) -> exact cut, then one ordered
 //                  compaction pass (ties at the cut resolved towards the lower list index).
 #include <cstddef>
+#include <cstdlib>
 
 #include "hess_dev.h"
 #include "hess_devmath.h"
@@ -1170,12 +1171,21 @@ void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const
 }
 
 bool extrema_scatter_scans(const Geom& g) { return g.NR <= SC_MAXROWS; }
+static int scatter_scan_policy() {  // HESS_SCATTER_SCAN: 1 = always scan in the scatter launch, 0 = never, unset = by batch size
+  static const int v = [] { const char* e = getenv("HESS_SCATTER_SCAN"); return e ? atoi(e) : -1; }();
+  return v;
+}
 
 void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const LimitParams& lp, const float* gauss,
                             const float* deth, const uint64_t* rowmask, const int* rowcnt, int* rowoff, int* level_count,
                             int* raw_total, int* overflow, RawKey* raw, int cap_raw, int batch, unsigned* hist, int topk) {
   const dim3 grid((cap_raw + 255) / 256, batch);
-  if (extrema_scatter_scans(g)) {  // the scatter workgroups scan the row counts themselves (LDS)
+  // One or two images: the scatter workgroups scan the row counts themselves, in LDS (a 12 us single-workgroup launch
+  // less in the image's dependent chain).  Larger batches keep row_scan_kernel: every scatter workgroup repeating the
+  // scan is 512 scans instead of 8 for a batch of eight, and six pipelined contexts lose 2 % to it (18.06 - 18.10
+  // against 18.36 - 18.53 Gpix/s, same call) -- on a saturated device the redundant work costs more than the launch.
+  const int pol = scatter_scan_policy();
+  if (extrema_scatter_scans(g) && (pol < 0 ? batch <= 2 : pol > 0)) {
     hipLaunchKernelGGL(extrema_scatter_kernel<true>, grid, dim3(256), 0, st, g, dp, lp, gauss, deth, rowmask, rowcnt,
                        raw_total, level_count, overflow, raw, cap_raw, hist, topk);
     return;

@@ -50,6 +50,8 @@ def main():
             kw["first_octave"] = 1
         if rng.rand() < 0.2:
             kw["subpixel"] = 0
+        if rng.rand() < 0.3:
+            kw["descriptor_order"] = 1    # the reference's sequential summation order (default: interleaved)
         g = hessgpu_amd.HessContext(0, **kw)
         o = OracleSession(threads=16, **kw)
         try:

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Phase shares of the Gaussian kernel from a diagnostic build (-DHESS_GAUSS_STAMPS=1, k_gauss.hip).
+"""Phase shares of the Gaussian kernel from a diagnostic build (-DHESS_GAUSS_STAMPS=1).  Round-3 tool: the stamps and the
+column-strip march they were written for left k_gauss.hip in round 4; apply profiles/r03_experiments/gauss_march.diff
+(patch -p0 from the repo root, against the round-3 file) to get a tree this script works on.
 
     python -m hessgpu_amd.build --variant stamps_tiles -DHESS_GAUSS_STAMPS=1 -DHESS_GAUSS_TILES=1
     python -m hessgpu_amd.build --variant stamps_march -DHESS_GAUSS_STAMPS=1
