@@ -310,9 +310,9 @@ def main():
             c.run_device(d_imgs.data_ptr(), B, H, W)
         prof = c.profile()
         c.profile_enable(False)
-        # For comparison, the same leg with the other form of the descriptor launch: descriptor_kernel<true> also
+        # For comparison, the same leg with the other form of the descriptor launch: descriptor_kernel<true, ..> also
         # stores the results into pinned host memory (what batches of one or two images use by default; alone on the
-        # device it waits for PCIe), descriptor_kernel<false> leaves them in HBM for the copier thread's DMA copy.
+        # device it waits for PCIe), descriptor_kernel<false, ..> leaves them in HBM for the copier thread's DMA copy.
         saved = os.environ.get("HESS_DELIVERY")
         os.environ["HESS_DELIVERY"] = "dma" if _mirror_is_default(B) else "mirror"   # the other form
         cd = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
@@ -553,7 +553,7 @@ def configs4_leg(local_rank, torch):
         "Mpix_per_s_three_contexts": round(S * S / dt / 1e6, 1), "ms_per_image_three_contexts": round(dt * 1e3, 3),
         "kernel_ms_per_image": {k: round(v["ms"] / 5, 4) for k, v in prof.items() if v["launches"]},
         "roofline_descriptor": {
-            "bound": "hbm", "kernel": "descriptor_kernel<false> (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
+            "bound": "hbm", "kernel": "descriptor_kernel<false, false> (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / dur / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1), "features_per_launch": n,
         },
@@ -641,9 +641,10 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
         nfeat = int(round(nfeat / per_step))
         dur = d["ms"] * 1e-3 / d["launches"]
         achieved = fbytes / dur / 1e9
-        names = {False: "descriptor_kernel<false> (one wavefront per feature: rotated-grid histogram + normalisation + packed "
+        # (kernel names as a rocprofv3 trace prints them: descriptor_kernel<host mirror, sequential order>)
+        names = {False: "descriptor_kernel<false, false> (one wavefront per feature: rotated-grid histogram + normalisation + packed "
                         "result stores in HBM; the copier thread's DMA copy takes them to the host)",
-                 True: "descriptor_kernel<true> (one wavefront per feature: rotated-grid histogram + normalisation + result "
+                 True: "descriptor_kernel<true, false> (one wavefront per feature: rotated-grid histogram + normalisation + result "
                        "stores incl. the pinned host mirror)"}
         e = {
             "bound": "hbm",
@@ -665,9 +666,9 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
             e["without_host_mirror" if mirror else "with_host_mirror"] = {
                 "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(dbytes / ddur / 1e9, 1), "unit": "GB/s",
                 "launches_per_step": max(1, round(dd["launches"] / steps)),
-                "kernel": "descriptor_kernel<false>" if mirror else "descriptor_kernel<true>",
+                "kernel": "descriptor_kernel<false, false>" if mirror else "descriptor_kernel<true, false>",
                 "note": "same launch on a context created with HESS_DELIVERY=" + ("dma" if mirror else "mirror") +
-                        ": descriptor_kernel<true> also stores keypoints + descriptors into pinned host memory and, "
+                        ": descriptor_kernel<true, ..> also stores keypoints + descriptors into pinned host memory and, "
                         "alone on the device, waits for PCIe",
             }
         out.append(e)

@@ -39,7 +39,7 @@ def main():
         raise SystemExit(f"make_profile_json: {traffic['valu_insts_per_image']} vector instructions per image is not plausible")
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
-    dk = dd["kernel"].split()[0]  # the form the benched batch size uses: descriptor_kernel<false> (copier delivery) or <true> (host mirror)
+    dk = dd["kernel"].split(" (")[0]  # the form the benched batch size uses: descriptor_kernel<false> (copier delivery) or <true> (host mirror)
     r = rows[dk]
     feats = dd["features_per_launch"]
     f = lambda k: float(r[k])
@@ -60,10 +60,45 @@ def main():
     }
     json.dump(out, open(os.path.join(ROOT, "profiles", "descriptor_counters.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    extrema_table(d, tag, rows, traffic)
     top = kernel_stats_top(d, tag, bench)
     if top:
         json.dump(top, open(os.path.join(ROOT, "profiles", "kernel_stats_top.json"), "w"), indent=1)
         print(json.dumps(top, indent=1))
+
+
+def extrema_table(d, tag, rows, traffic):
+    """profiles/<tag>_extrema_counters.md: the extrema scan read off its counters: where its wavefronts'
+    time goes, per launch, from the two SQ passes and the traffic passes of tools/profile_round.sh."""
+    k = next((n for n in rows if n.startswith("extrema_stream_kernel")), None)
+    if not k:
+        return
+    r = {a: float(b) for a, b in rows[k].items() if a not in ("kernel",) and b not in ("", "nan")}
+    wc = r["SQ_WAVE_CYCLES"]
+    tr = next((p for p in traffic["per_kernel"] if p["kernel"] == k), None)
+    clock = {}
+    cpath = os.path.join(d, "clock.csv")
+    if os.path.exists(cpath):
+        clock = {x["kernel"]: x for x in csv.DictReader(open(cpath))}
+    us = float(clock[k]["avg_us"]) if k in clock else None
+    lines = [f"# {k}: counters per launch ({tag}; batches of eight 1080p images, one stream)", "",
+             "| Quantity | Value | Share of wavefront time |", "|---|---|---|",
+             f"| launches in the pass / wavefronts per launch | {int(r['launches'])} / {r['SQ_WAVES']:.0f} | |",
+             f"| SQ_WAVE_CYCLES (quad-cycles summed over the wavefronts) | {wc:.4g} ({wc / r['SQ_WAVES']:.0f} per wavefront) | 1 |",
+             f"| SQ_WAIT_ANY (in s_waitcnt: loads, LDS, scalar memory) | {r['SQ_WAIT_ANY']:.4g} | {r['SQ_WAIT_ANY'] / wc:.3f} |",
+             f"| SQ_WAIT_INST_ANY (ready, waiting for an issue slot) | {r['SQ_WAIT_INST_ANY']:.4g} | {r['SQ_WAIT_INST_ANY'] / wc:.3f} |",
+             f"| SQ_ACTIVE_INST_VALU (issuing vector instructions) | {r['SQ_ACTIVE_INST_VALU']:.4g} | {r['SQ_ACTIVE_INST_VALU'] / wc:.3f} |",
+             f"| SQ_ACTIVE_INST_ANY | {r['SQ_ACTIVE_INST_ANY']:.4g} | {r['SQ_ACTIVE_INST_ANY'] / wc:.3f} |",
+             f"| SQ_INSTS_VALU | {r['SQ_INSTS_VALU']:.4g} ({r['SQ_INSTS_VALU'] / r['SQ_WAVES']:.0f} per wavefront) | |",
+             f"| SQ_INSTS_SALU / SQ_INSTS_VMEM_RD / SQ_INSTS_LDS | {r.get('SQ_INSTS_SALU', 0):.4g} / {r.get('SQ_INSTS_VMEM_RD', 0):.4g} / {r.get('SQ_INSTS_LDS', 0):.4g} | |"]
+    if tr:
+        lines.append(f"| HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes) | {tr['hbm_bytes_per_launch_corrected'] / 1e6:.1f} MB | |")
+    if us:
+        lines.append(f"| kernel time (GRBM pass) / effective clock | {us:.1f} us / {clock[k]['effective_clock_ghz']} GHz | |")
+    lines += ["", "Verdict: the wavefronts wait (s_waitcnt) for two thirds of their time and issue vector instructions for a fifth of it at "
+              "three wavefronts per SIMD: the scan is bound by memory, not by instruction issue.  What kind of memory bound, and "
+              "the experiments that separate the readings: profiles/r04_experiments/extrema_scan.txt, profiles/r04_strided_streams.txt.", ""]
+    open(os.path.join(ROOT, "profiles", f"{tag}_extrema_counters.md"), "w").write("\n".join(lines))
 
 
 def short(name):
@@ -89,7 +124,7 @@ def kernel_stats_top(d, tag, bench):
     name = short(r["Name"])
     avg_s = float(r["AverageNs"]) * 1e-9
     entries = [bench.get("roofline"), bench.get("roofline_secondary")]
-    e = next((x for x in entries if x and x["kernel"].split()[0].startswith(name.split("<")[0])), None)
+    e = next((x for x in entries if x and x["kernel"].split(" (")[0].startswith(name.split("<")[0])), None)
     if e is None:
         return None
     out = {

@@ -18,9 +18,10 @@ def main():
         name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("hess::", ""))
         a = agg[name]
         a[0] += float(r["Counter_Value"]); a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); a[2] += 1
-    print("kernel,launches,avg_us,gui_active_per_launch,effective_clock_ghz")
+    w = csv.writer(sys.stdout)   # (kernel names carry commas: quoted)
+    w.writerow(["kernel", "launches", "avg_us", "gui_active_per_launch", "effective_clock_ghz"])
     for n, (v, d, k) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{n},{k},{d / k / 1e3:.2f},{v / k:.4g},{(v / 8.0) / d:.3f}")
+        w.writerow([n, k, f"{d / k / 1e3:.2f}", f"{v / k:.4g}", f"{(v / 8.0) / d:.3f}"])
 
 
 if __name__ == "__main__":
