@@ -741,11 +741,17 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // NOT for larger batches: a batch of 8 is 2 % faster on one stream with octaves >= 2 chained, but six pipelined
   // contexts lose 2 - 4 % (15.5 - 15.6 against 16.1 - 16.2 Gpix/s, same call; 15.8 - 16.0 with octaves >= 3) -- the chain
   // trades dependent launches for redundant arithmetic in 1024-thread workgroups that wait at barriers, which is what
-  // an idle device wants and a saturated one does not.  Needs the default schedule's tap counts.
+  // an idle device wants and a saturated one does not; and not for the large octaves of a large image (a 4096^2 image's
+  // octave 1 is 4 096 such workgroups: configs[4] 2.19 against 2.12 ms).  Needs the default schedule's tap counts.
   // HESS_CHAIN_FROM=n forces the first chained octave (99: never).
   int chain_from = g.noct;
   if (fused_decim && s.level_max == s.level_ds + 1 && gauss_chain_available(s.taps, s.level_ds)) {
-    chain_from = c->chain_from > 0 ? c->chain_from : (batch <= 2 ? 1 : g.noct);
+    chain_from = c->chain_from;
+    if (chain_from <= 0) {  // by size: the first octave (>= 1) whose planes of the whole batch are at most two 960x540 planes
+      chain_from = g.noct;
+      if (batch <= 2)
+        for (int o = g.noct - 1; o >= 1 && (long long)batch * g.o[o].plane <= 2LL * 960 * 540; o--) chain_from = o;
+    }
     if (chain_from > g.noct) chain_from = g.noct;
   }
   const bool chained = chain_from < g.noct;
