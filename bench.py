@@ -63,8 +63,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[3]: 64 images over 8 GPUs)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images per GPU (0 = --batch: all distinct)")
-    ap.add_argument("--contexts", type=int, default=6, help="contexts (streams) pipelined per GPU (with the copier-thread delivery a "
-                    "context's stream idles while its results are copied: six keep the device busy, profiles/r03_delivery.txt)")
+    ap.add_argument("--contexts", type=int, default=7, help="contexts (streams) pipelined per GPU (with the copier-thread delivery a "
+                    "context's stream idles while its results are copied; round 4, same call, 200 steps: 4: 16.5, 5: 17.2, 6: 17.5 - 18.1, "
+                    "7: 17.8 - 18.4, 8: 17.1, 9: 18.0, 10: 17.7, 11: 18.4, 13: 18.2 Gpix/s -- the streams share four hardware queues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")

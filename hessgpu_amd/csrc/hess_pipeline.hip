@@ -757,7 +757,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   const bool chained = chain_from < g.noct;
   GaussJob top_jobs[kMaxOct];  // the top levels of the octaves that do not ride with the next octave's level 1
   int ntop = 0;
-  double top_bytes = 0.0, top_bytes_oct0 = 0.0;
+  double top_bytes = 0.0;
   int deferred_o = -1;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
@@ -810,7 +810,6 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       if (l == s.level_max && chained && o + 1 >= chain_from) {  // with the chained octaves' top levels, after the chain
         top_jobs[ntop++] = level_job(o, l);
         top_bytes += level_bytes(o, l);
-        if (o == 0) top_bytes_oct0 = level_bytes(o, l);
         continue;
       }
       if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
@@ -823,7 +822,6 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     launch_level(level_job(deferred_o, s.level_max));
   }
   if (ntop) {  // the top levels left over by the chain, one launch
-    (void)top_bytes_oct0;
     ProfScope ps(c, HESS_K_GAUSS, top_bytes);
     // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves, from HBM: hessian_low_levels)
     LowLevels low{&g, gauss, deth, got, s.norm, chain_from, chained ? s.level_ds : 0};

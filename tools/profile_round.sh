@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics, single stream (averages comparable with bench.py's hipEvent roofline leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ctx1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > $OUT/bench_ctx1.json 2> $OUT/bench_ctx1.err
-# 2. kernel statistics, default pipelined contexts (six)
+# 2. kernel statistics, default pipelined contexts (seven since round 4)
 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-host-leg --no-api-leg --no-configs4 > $OUT/bench_ctxd.json 2> $OUT/bench_ctxd.err
 # 3./4. HBM traffic counters, one pass each
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_fetch.err
