@@ -1,0 +1,55 @@
+"""The committed PMC / trace summaries that bench.py copies numbers from (profiles/*.json) are plausible and agree with the
+committed kernel table they were distilled from.  Round 3 published a vector-issue fraction of 15.94 because one of these
+files was wrong by a factor of 68 and nothing looked at it without a GPU."""
+import csv
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def _j(name):
+    with open(os.path.join(P, name)) as f:
+        return json.load(f)
+
+
+def test_gauss_traffic_is_plausible():
+    t = _j("gauss_traffic.json")
+    # a 1080p pyramid with its fused det-H / gradient stage: 1.5e7 - 2.5e7 vector instructions per image
+    assert 1.0e7 < t["valu_insts_per_image"] < 3.0e7, t["valu_insts_per_image"]
+    assert t["valu_insts_steps_in_pass"] >= 1
+    # HBM traffic per launch within a few per cent of the algorithmic bytes (each level read once, written once)
+    assert 0.95 < t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.15
+    # the nominal issue peak cannot be exceeded by the rate this implies at the committed kernel time (about 0.5 ms per
+    # step of eight images): instructions x 8 / 0.5 ms < 1228.8 Ginst/s
+    assert t["valu_insts_per_image"] * 8 / 0.5e-3 / 1e9 < 1228.8
+
+
+def test_descriptor_counters_are_plausible():
+    d = _j("descriptor_counters.json")
+    assert 3.0e3 < d["valu_insts_per_feature"] < 1.2e4
+    assert 0.0 < d["wave_time_issuing_valu"] < 1.0 and 0.0 < d["wave_time_waiting"] < 1.0
+    assert d["wave_time_issuing_valu"] + d["wave_time_waiting"] + d["wave_time_issue_stalled"] <= 1.0
+    assert 0.3 < d["hbm_bytes_per_launch"] / d["algorithmic_bytes_per_launch"] < 2.0
+    assert abs(d["valu_insts_per_launch"] / d["features_per_launch"] - d["valu_insts_per_feature"]) < 1.0
+
+
+def test_kernel_stats_top_is_the_top_row_of_the_committed_table():
+    top = _j("kernel_stats_top.json")
+    assert 0.0 < top["frac"] <= 1.0 and abs(top["frac"] - top["achieved"] / top["peak"]) < 1e-3
+    m = re.search(r"profiles/(\S+_kernel_stats_contexts1\.csv)", top["source"])
+    assert m, top["source"]
+    rows = [r for r in csv.DictReader(open(os.path.join(P, m.group(1)))) if "hess::" in r["Name"]]
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    name = re.sub(r"\(.*", "", rows[0]["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("hess::", ""))
+    assert top["kernel"].startswith(name.split("<")[0])
+    if top["kernel"] == name:
+        assert abs(top["avg_launch_us"] - float(rows[0]["AverageNs"]) / 1e3) < 0.05
+        assert abs(top["achieved"] - top["algorithmic_bytes_per_launch"] / (top["avg_launch_us"] * 1e-6) / 1e9) < 1.0
+
+
+def test_chip_constants_used_by_the_bench_line():
+    assert 800.0 < _j("valu_peak.json")["sustained_fma_ginst_all_cus"] <= 1228.8
+    assert 3000.0 < _j("hbm_mix.json")["one_read_four_writes_gbs"] < 8000.0
