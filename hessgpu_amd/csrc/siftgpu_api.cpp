@@ -6,7 +6,9 @@
 #include "../../include/SiftGPU.h"
 
 #include <ctype.h>
+#include <dlfcn.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -124,6 +126,55 @@ bool load_pnm(const char* path, std::vector<unsigned char>& out, int& w, int& h)
   }
   fclose(f);
   return ok;
+}
+
+// PNG files through libpng's "simplified API" (png.h of libpng 1.6: png_image_begin_read_from_file / _finish_read /
+// _free), looked up at RUN time: the reference decodes files with DevIL (GLTexImage.cpp:1117-1158) and hands the decoded
+// pixels in the file's own layout to SetImageData, which is what happens here -- grey, grey + alpha, RGB or RGBA, 8 bits
+// (16-bit and palette files are converted to those by libpng).  No build dependency: the image this was written on has
+// libpng16.so.16 and no headers; png_image is the documented, versioned public struct of that API.  Returns 0: not a PNG
+// file; -1: a PNG file that cannot be read (library missing or decode error, message on stderr); else the HESS_FMT_*.
+struct PngImage {
+  void* opaque;
+  uint32_t version, width, height, format, flags, colormap_entries;
+  uint32_t warning_or_error;
+  char message[64];
+};
+int load_png(const char* path, std::vector<unsigned char>& out, int& w, int& h) {
+  unsigned char sig[8] = {0};
+  FILE* f = fopen(path, "rb");
+  if (!f) return 0;
+  const bool is_png = fread(sig, 1, 8, f) == 8 && !memcmp(sig, "\x89PNG\r\n\x1a\n", 8);
+  fclose(f);
+  if (!is_png) return 0;
+  typedef int (*begin_fn)(PngImage*, const char*);
+  typedef int (*finish_fn)(PngImage*, const void*, void*, int32_t, void*);
+  typedef void (*free_fn)(PngImage*);
+  static void* lib = dlopen("libpng16.so.16", RTLD_LAZY | RTLD_LOCAL);
+  static begin_fn begin = lib ? (begin_fn)dlsym(lib, "png_image_begin_read_from_file") : nullptr;
+  static finish_fn finish = lib ? (finish_fn)dlsym(lib, "png_image_finish_read") : nullptr;
+  static free_fn release = lib ? (free_fn)dlsym(lib, "png_image_free") : nullptr;
+  if (!begin || !finish || !release) {
+    std::cerr << "PNG file, but libpng16.so.16 is not available at run time: " << path << "\n";
+    return -1;
+  }
+  PngImage img;
+  memset(&img, 0, sizeof(img));
+  img.version = 1;  // PNG_IMAGE_VERSION
+  if (!begin(&img, path)) { std::cerr << "libpng: " << img.message << ": " << path << "\n"; return -1; }
+  const bool colour = (img.format & 0x02u) != 0, alpha = (img.format & 0x01u) != 0;  // PNG_FORMAT_FLAG_COLOR / _ALPHA
+  img.format = (colour ? 0x02u : 0u) | (alpha ? 0x01u : 0u);  // PNG_FORMAT_GRAY / GA / RGB / RGBA: 8-bit, no colour map
+  const int ch = (colour ? 3 : 1) + (alpha ? 1 : 0);
+  w = (int)img.width; h = (int)img.height;
+  try {
+    out.assign((size_t)w * h * ch, 0);
+  } catch (...) { release(&img); return -1; }
+  if (!finish(&img, nullptr, out.data(), 0, nullptr)) {
+    std::cerr << "libpng: " << img.message << ": " << path << "\n";
+    release(&img);
+    return -1;
+  }
+  return ch == 1 ? HESS_FMT_LUM : ch == 2 ? HESS_FMT_LUM_ALPHA : ch == 3 ? HESS_FMT_RGB : HESS_FMT_RGBA;
 }
 
 }  // namespace
@@ -271,8 +322,8 @@ void SiftGPU::PrintUsage() {
                "-half -sd -b -bvlf -ads -maxd <n> -p WxH -tight -cuda <dev> -v <0..4>\n"
                "-dseq                                    descriptor bins summed in the reference's sequential order\n"
                "                                         (default: four interleaved partial sums, 16 % faster, equal within 1e-6)\n"
-               "Image files: PGM / PPM (P2 P3 P5 P6) only -- this build has no DevIL; convert JPEG / PNG first, or hand\n"
-               "the decoded pixels to RunSIFT(width, height, data, gl_format, gl_type).\n";
+               "Image files: PGM / PPM (P2 P3 P5 P6), and PNG when libpng16.so.16 is present at run time -- this build has no\n"
+               "DevIL; decode JPEG in the caller and hand the pixels to RunSIFT(width, height, data, gl_format, gl_type).\n";
 }
 
 void SiftGPU::SetVerbose(int verbose) {  // SiftGPU.cpp:433-464
@@ -535,11 +586,17 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
   im->keys.clear();
   im->desc.clear();
   if (_image_loaded == 0) {
-    if (!load_pnm(_imgpath, im->pixels, im->w, im->h)) {
-      std::cerr << "Unable to open image (this build reads PGM/PPM only): " << _imgpath << "\n";
+    const int png = load_png(_imgpath, im->pixels, im->w, im->h);
+    if (png < 0) return 0;
+    if (png > 0) {
+      im->fmt = png;
+    } else if (load_pnm(_imgpath, im->pixels, im->w, im->h)) {
+      im->fmt = HESS_FMT_LUM;
+    } else {
+      std::cerr << "Unable to open image (this build reads PGM / PPM and, with libpng16 present at run time, PNG; decode "
+                   "JPEG in the caller and use RunSIFT(width, height, data, gl_format, gl_type)): " << _imgpath << "\n";
       return 0;
     }
-    im->fmt = HESS_FMT_LUM;
     im->pix = HESS_PIX_U8;
     im->pixels_in_ctx = false;
     if (im->verbose) std::cout << "Image loaded :\t" << _imgpath << "\n";

@@ -143,3 +143,38 @@ def test_failed_run_leaves_no_stale_results():
     assert g.run(lum[None])[0] == n_good
     g.close()
     s.close()
+
+
+@pytest.mark.parametrize("name,params", [("sunflowers.png", ["-t", "0.02", "-topk", "10"]), ("blobs.png", []),
+                                         ("checkerboard.png", ["-t", "0.000001", "-topk", "500"])])
+def test_png_files_are_read_through_libpng_at_run_time(name, params):
+    """RunSIFT(path) on the reference's own PNG demo inputs: decoded by libpng16 (dlopen, no build dependency) into the
+    file's own layout (RGB; RGBA for the checkerboard's tRNS) and handed to the conversion the reference's DevIL path
+    feeds (GLTexImage.cpp:1136-1142 -> SetImageData) -- same features as the oracle on PIL-decoded pixels."""
+    s = siftgpu_lib.SiftGPU(["-maxd", "4096"] + params)
+    assert s.run_file(os.path.join(fixtures._DATA, name)) == 1
+    k, d = s.features()
+    kw = {}
+    it = iter(params)
+    for a in it:
+        v = next(it)
+        if a == "-t":
+            kw["dog_threshold"] = float(v)
+        if a == "-topk":
+            kw.update(truncate_method=3, feature_count_threshold=int(v))
+    o = OracleSession(threads=16, keep_levels=False, tex_max_dim=4096, **kw)
+    o.run(fixtures.load_rgb(name)[None])
+    ok, od = o.fetch(0)
+    assert len(k) == len(ok) > 0 and k.tobytes() == ok.tobytes() and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    s.close()
+
+
+def test_unreadable_files_return_zero(tmp_path):
+    s = siftgpu_lib.SiftGPU([])
+    assert s.create_context() == 2
+    bad = tmp_path / "broken.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"not a png at all")
+    assert s.run_file(str(bad)) == 0 and s.L.siftgpu_feature_num(s.h) == 0
+    assert s.run_file(os.path.join(fixtures._DATA, "640-1.jpg")) == 0      # JPEG: not decoded by this build
+    assert s.run_file(str(tmp_path / "missing.pgm")) == 0
+    s.close()
