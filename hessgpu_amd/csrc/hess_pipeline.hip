@@ -580,8 +580,8 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
     // it they grow on demand once the counts are known (wait_impl / the copier), and the in-kernel mirror is not used.
     const size_t host_bytes = (size_t)B * cap_feat * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
     // Node-shared result buffers of a batch the copier delivers are sized by the batches seen (+ 25 %), not for the
-    // worst case B * cap_feat: six contexts x eight ranks x 79 MB of worst case were 3.8 GB of /dev/shm for 1.2 GB of
-    // results; the copier (or hess_wait) grows them under a new generation when a batch needs more.
+    // worst case B * cap_feat: 79 MB per context, 3.8 - 4.4 GB of /dev/shm for a node's six or seven contexts x eight
+    // ranks, where the results are 24 MB per context; the copier (or hess_wait) grows them under a new generation when a batch needs more.
     c->share_by_need = c->share_dir && B > c->mirror_max_batch && c->delivery_pref != kDeliverMirror;
     c->host_fits = !c->share_by_need && host_bytes <= ((size_t)512 << 20);
     if (c->host_fits) {
