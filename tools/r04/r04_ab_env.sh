@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-call A/B of environment switches of the in-tree library:  tools/r04_ab_env.sh TAG "VAR=val ..." "VAR=val ..." ...
+# Same-call A/B of environment switches of the in-tree library:  tools/r04/r04_ab_env.sh TAG "VAR=val ..." "VAR=val ..." ...
 # ("-" = no switch).  Each setting: bench.py --steps 200 without the side legs; prints value, ms/step and the per-kernel sums.
 TAG=$1; shift
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE per launch of the kernels matching $1 for library builds $2.. (same call): tools/r04_fetch.sh extrema cur variant
+# FETCH_SIZE per launch of the kernels matching $1 for library builds $2.. (same call): tools/r04/r04_fetch.sh extrema cur variant
 R=${GRAFT_REPO_ROOT:-$PWD}; K=$1; shift; cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = "cur" ]; then unset HESS_LIB; else export HESS_LIB=$R/tools/_variants/$v/libhessgpu.so; fi

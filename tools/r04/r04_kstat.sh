@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel statistics (single stream, batch of 8) of one or more library builds, same call: tools/r04_kstat.sh lib...
+# rocprofv3 kernel statistics (single stream, batch of 8) of one or more library builds, same call: tools/r04/r04_kstat.sh lib...
 R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = "cur" ]; then unset HESS_LIB; else export HESS_LIB=$R/tools/_variants/$v/libhessgpu.so; fi

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel statistics (single stream, batch of 8) under environment settings, same call: tools/r04_kstat_env.sh "VAR=v" ...
+# rocprofv3 kernel statistics (single stream, batch of 8) under environment settings, same call: tools/r04/r04_kstat_env.sh "VAR=v" ...
 R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   n=$(echo "$v" | tr ' =/' '___' | tail -c 40); rm -rf /tmp/kse_$n
