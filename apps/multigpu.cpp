@@ -70,7 +70,11 @@ struct Shared {
   std::vector<std::vector<int>> counts;             // per device, per image
   std::vector<std::vector<hess_keypoint>> host_keys;  // per device: its own host results of the last step (the check)
   std::vector<std::vector<float>> host_desc;
-  std::vector<int> failed;
+  // failure flags, read only after the barrier that follows their writes: `failed` before the gather (set before the
+  // counts barrier), `failed_after` by the gather itself (set before the end-of-step barrier) -- two arrays, so that a
+  // slow thread still reading one never sees a fast thread's later write
+  std::vector<int> failed, failed_after;
+  std::vector<int> result;  // per device, written once when its thread is done; read after the joins
   double seconds = 0.0;
   long long gathered_features = 0;
   bool gather_ok = true;
@@ -102,10 +106,10 @@ void device_thread(Shared* S, int dev) {
   // device 0: landing buffers for the other devices' lists, grown on demand
   std::vector<void*> land_keys(S->ndev, nullptr), land_desc(S->ndev, nullptr);
   std::vector<size_t> land_cap(S->ndev, 0);
-  S->failed[dev] = fail;
+  S->failed_after[dev] = fail;  // (set-up counts as the end of a step before the first)
   S->bar->wait();
   bool any_failed = false;
-  for (int f : S->failed) any_failed = any_failed || f;
+  for (int f : S->failed_after) any_failed = any_failed || f;
   const auto t0 = std::chrono::steady_clock::now();
   for (int step = 0; step < S->steps && !any_failed; step++) {
     const void *dk = nullptr, *dd = nullptr;
@@ -117,7 +121,7 @@ void device_thread(Shared* S, int dev) {
     }
     for (int b = 0; b < B; b++) S->counts[dev][b] = fail ? 0 : hess_count(ctx, b);
     S->totals[dev] = fail ? 0 : total;
-    S->dim = hess_desc_dim(ctx);
+    if (dev == 0) S->dim = hess_desc_dim(ctx);  // (same parameters on every device: written once)
     S->failed[dev] = fail;
     S->bar->wait();  // every device's counts are in the table
     for (int f : S->failed) any_failed = any_failed || f;
@@ -149,7 +153,7 @@ void device_thread(Shared* S, int dev) {
     }
     NCCL_OK(ncclGroupEnd());
     HIP_OK(hipStreamSynchronize(st));
-    S->failed[dev] = fail;
+    S->failed_after[dev] = fail;
     if (step == S->steps - 1 && !fail) {  // the last step's own host results, for the check below
       S->host_keys[dev].resize((size_t)total + 1);
       S->host_desc[dev].resize(((size_t)total + 1) * (size_t)(dim ? dim : 1));
@@ -160,7 +164,7 @@ void device_thread(Shared* S, int dev) {
       }
     }
     S->bar->wait();  // the step is over on every device (and the contexts may overwrite their result buffers)
-    for (int f : S->failed) any_failed = any_failed || f;
+    for (int f : S->failed_after) any_failed = any_failed || f;  // every thread sees the same flags: all leave together
   }
   if (dev == 0 && !any_failed) {
     S->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -185,7 +189,7 @@ void device_thread(Shared* S, int dev) {
   if (d_px) (void)hipFree(d_px);
   if (ctx) hess_destroy(ctx);
   if (st) (void)hipStreamDestroy(st);
-  S->failed[dev] = S->failed[dev] || fail;
+  S->result[dev] = fail;
 }
 
 }  // namespace
@@ -227,6 +231,8 @@ int main(int argc, char** argv) {
   S.counts.assign(S.ndev, std::vector<int>(S.batch, 0));
   S.host_keys.resize(S.ndev); S.host_desc.resize(S.ndev);
   S.failed.assign(S.ndev, 0);
+  S.failed_after.assign(S.ndev, 0);
+  S.result.assign(S.ndev, 0);
   Barrier bar(S.ndev);
   S.bar = &bar;
   printf("multigpu: %d device(s), %d image(s) of %dx%d per device and step, %d steps, top-K %d\n", S.ndev, S.batch, S.w, S.h,
@@ -236,7 +242,7 @@ int main(int argc, char** argv) {
   for (auto& t : threads) t.join();
   for (int d = 0; d < S.ndev; d++) ncclCommDestroy(S.comms[d]);
   bool ok = S.gather_ok;
-  for (int f : S.failed) ok = ok && !f;
+  for (int f : S.result) ok = ok && !f;
   if (ok) {
     for (int d = 0; d < S.ndev; d++) {
       printf("#%d:", d);

@@ -239,7 +239,8 @@ void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& d
 // look-back over the chunk counts).  scratch: topk_scratch_bytes(cap_raw, batch, nlev) bytes of device memory that
 // arrive ZEROED (tickets, chunk words, kept entries per level).
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total,
-                 int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch);
+                 int cap_raw, unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch,
+                 int* overflow);  // overflow[2]: raised when the look-back over the chunk words does not complete
 size_t topk_scratch_bytes(int cap_raw, int batch, int nlev);
 
 // Orientation (ComputeOrientation_Kernel, ProgramCU.cu:1221-1605): one wavefront per keypoint.

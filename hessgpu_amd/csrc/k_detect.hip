@@ -1002,11 +1002,12 @@ __device__ __forceinline__ void topk_classify(const RawKey* in, int i0, int n, i
 }
 
 constexpr unsigned long long TK_FLAG = 1ull << 40;
+constexpr int TK_SPIN_LIMIT = 1 << 21;  // polls of a predecessor's word, about half a microsecond apart: a second
 
 __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
                                                            const unsigned* hist, int* ticket, unsigned long long* state,
                                                            RawKey* sel, int* sel_total, int* sel_level_count, int cap_sel,
-                                                           int nchunk) {
+                                                           int nchunk, int* overflow) {
   __shared__ int lds[64];
   __shared__ int lc[kMaxOct * kMaxDog];
   __shared__ int s_cut, s_need, s_ck, s_sure0, s_ties0;
@@ -1034,9 +1035,18 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(Geom g, int K, const 
                        __HIP_MEMORY_SCOPE_AGENT);
   // look-back over the chunks before this one
   int ps = 0, pt = 0;
+  // (a predecessor publishes before it waits for anything, and ticket order means it is already running: the wait is
+  // short.  It is bounded all the same -- a word that never gets its flag, e.g. scratch that was not cleared, must end
+  // as an error the host reports (word 2 of the overflow block -> HESS_ERR_DEVICE, as the reference returns 0 on device
+  // errors, SiftPyramid.h:162-163), not as a hung stream; the poll sleeps between loads so that 1 024 spinning lanes
+  // leave the memory path to the workgroups they wait for.)
   for (int k = tid; k < ck; k += 1024) {
-    unsigned long long v;
-    do { v = __hip_atomic_load(&st[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & TK_FLAG));
+    unsigned long long v = __hip_atomic_load(&st[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; !(v & TK_FLAG) && spin < TK_SPIN_LIMIT; spin++) {
+      __builtin_amdgcn_s_sleep(8);
+      v = __hip_atomic_load(&st[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!(v & TK_FLAG)) { atomicMax(overflow + 2, 1); v = 0; }
     ps += (int)((v >> 20) & 0xFFFFFu);
     pt += (int)(v & 0xFFFFFu);
   }
@@ -1198,13 +1208,13 @@ int topk_chunks(int cap_raw) { return (cap_raw + TK_CHUNK - 1) / TK_CHUNK; }
 // scratch (topk_scratch_bytes; must arrive zeroed): [ticket: batch ints, padded to 8 bytes][state: batch x nchunk
 // 64-bit words][sel_level_count: batch x nlev ints]
 void launch_topk(hipStream_t st, const Geom& g, int K, const RawKey* raw, const int* raw_total, int cap_raw,
-                 unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch) {
+                 unsigned* hist, RawKey* sel, int* sel_total, int cap_sel, int batch, void* scratch, int* overflow) {
   const int nchunk = topk_chunks(cap_raw);
   int* ticket = reinterpret_cast<int*>(scratch);
   unsigned long long* state = reinterpret_cast<unsigned long long*>(ticket + ((batch + 1) & ~1));
   int* sel_level_count = reinterpret_cast<int*>(state + (size_t)batch * nchunk);
   hipLaunchKernelGGL(topk_select_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, K, raw, raw_total, cap_raw, hist,
-                     ticket, state, sel, sel_total, sel_level_count, cap_sel, nchunk);
+                     ticket, state, sel, sel_total, sel_level_count, cap_sel, nchunk, overflow);
 }
 
 size_t topk_scratch_bytes(int cap_raw, int batch, int nlev) {

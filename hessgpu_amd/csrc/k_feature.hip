@@ -838,7 +838,9 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   if (blocks < 1) blocks = 1;
   const int lds_pad = DC_LDS_PAD_BYTES;
   DescParams dpx = dp;
-  if (dpx.xcd_block && (blocks * 4) % (8 * dpx.xcd_block) != 0) dpx.xcd_block = 0;  // the block order needs whole blocks per XCD
+  // the block order needs whole blocks per XCD, and a grid of whole rounds over the eight XCDs (else the map from
+  // (XCD, wavefront in the XCD) to list blocks is not onto: features would be skipped and others computed twice)
+  if (dpx.xcd_block && ((blocks * 4) % (8 * dpx.xcd_block) != 0 || blocks % 8 != 0)) dpx.xcd_block = 0;
 #define HESS_DESC_LAUNCH(MIRROR, SEQ)                                                                                  \
   hipLaunchKernelGGL((descriptor_kernel<MIRROR, SEQ>), dim3(blocks, batch), dim3(256), lds_pad, st, g, dpx, list, cap_list, \
                      recs, fsrc, feat_total, feat_first, img_base, got, keys, desc, cap_feat)

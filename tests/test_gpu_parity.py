@@ -15,6 +15,27 @@ from oracle_lib import OracleSession
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # BASELINE.json north_star: "keypoints/descriptors matching reference within 1e-4"
+# The product's default descriptor order is not the reference's summation order (include/hess_abi.h,
+# hess_params.descriptor_order); on every BASELINE config it is tied to the reference's sequential order
+# (ProgramCU.cu:1723-1774, the oracle's descriptor_order=1) by this tolerance on unit-norm descriptors:
+TOL_ORDER = 1e-6
+
+
+def _assert_tied_to_reference_order(g, imgs, kw, what, threads=16):
+    """The context's results (already run on imgs, any descriptor order) against the oracle in the REFERENCE's
+    summation order: keypoints bitwise, descriptors within TOL_ORDER."""
+    o = OracleSession(threads=threads, keep_levels=False, descriptor_order=_abi.DESC_ORDER_SEQUENTIAL, **kw)
+    o.run(imgs)
+    worst = 0.0
+    for b in range(len(imgs)):
+        gk, gd = g.fetch(b)
+        ok, od = o.fetch(b)
+        assert gk.tobytes() == ok.tobytes(), f"{what}: img {b}: keypoints differ from the sequential-order oracle"
+        if od.size:
+            worst = max(worst, float(np.abs(gd.astype(np.float64) - od.astype(np.float64)).max()))
+    o.close()
+    assert worst <= TOL_ORDER, f"{what}: default order vs the reference's sequential order: max abs diff {worst}"
+    return worst
 
 
 def _assert_same_features(gk, gd, ok, od, what):
@@ -117,6 +138,7 @@ def test_parity_list640_sequence(gpu_ctx_factory):
     for name in fixtures.list640():
         img = fixtures.load_rgb(name)
         _compare_all(g, o, img[None], name, stages=False)
+        _assert_tied_to_reference_order(g, img[None], {}, name, threads=8)
 
 
 def test_parity_batch_of_images(gpu_ctx_factory):
@@ -144,6 +166,7 @@ def test_parity_1080p_topk(gpu_ctx_factory):
     o = OracleSession(threads=8, **kw)
     n = _compare_all(g, o, im[None], "1080p top-K 4096")
     assert len(o.rawlist(0)) == 4096 and n[0] >= 4096
+    _assert_tied_to_reference_order(g, im[None], kw, "1080p top-K 4096")
 
 
 def test_parity_4096_half_topk65536(gpu_ctx_factory):
@@ -155,6 +178,7 @@ def test_parity_4096_half_topk65536(gpu_ctx_factory):
     o = OracleSession(threads=16, keep_levels=False, **kw)
     n = _compare_all(g, o, im[None], "4096x4096 half top-K 65536", stages=False)
     assert len(o.geometry()) == 9 and len(o.rawlist(0)) == 65536 and n[0] >= 65536
+    _assert_tied_to_reference_order(g, im[None], kw, "4096x4096 half top-K 65536")
     k, d = g.fetch(0)
     assert d.shape[1] == 64
     # size-independent properties at full size: unit-norm descriptors, clamp, list order, top-K cut
