@@ -125,6 +125,7 @@ PRODUCT_PROTOTYPES = {
     "profile_get": (C.c_int, [_ctx, C.c_int, _P(C.c_double), _P(C.c_longlong), _P(C.c_double)]),
     "profile_reset": (C.c_int, [_ctx]),
     "debug_regrown": (C.c_int, [_ctx]),
+    "debug_keep_levels": (C.c_int, [_ctx, C.c_int]),
     "last_input": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "share_results": (C.c_int, [_ctx, C.c_char_p]),
     "shared_results_info": (C.c_int, [_ctx, _P(C.c_uint), _P(C.c_uint), _P(C.c_size_t), _P(C.c_size_t)]),

@@ -162,7 +162,14 @@ struct GaussJob {
   float norm_src;
   float* decim_dst;
   int decim_w, decim_h;
+  // a TOP level (the octave's top level): det-H * sigma^4 of the PRODUCED level from the output tile, `dst` may be null
+  // (the level is then never written to HBM); zero / zero_bytes: buffers to clear on the side (multiple of 16 bytes)
+  float* deth_dst = nullptr;
+  float norm_dst = 0.0f;
+  void* zero = nullptr;
+  size_t zero_bytes = 0;
 };
+void launch_gauss_job(hipStream_t st, const GaussJob& j, int batch);
 // Two independent level launches in one grid (the top level of an octave and level 1 of the next); false if the pair of
 // tap counts is not instantiated: launch them separately then.
 bool launch_gauss_pair(hipStream_t st, const GaussJob& a, const GaussJob& b, int batch);

@@ -201,6 +201,8 @@ struct hess_ctx {
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
+  bool no_top_fusion = false;      // HESS_NO_TOP_FUSION: the top level is stored and its det-H made by a launch of its own (A/B switch)
+  bool keep_levels = false;        // hess_debug_keep_levels: the top Gaussian level of every octave is written to HBM as well
   int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
   bool no_host_upload = false;     // HESS_NO_SIDE_UPLOAD: pinned input is uploaded by a copy on the context's stream (A/B switch)
   int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
@@ -709,6 +711,10 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // The launch that produces the down-sampling level also writes level 0 of the next octave (its even rows and
   // columns): no decimation launches.  (A down-sampling level 0 is nobody's product: separate kernel then.)
   const bool fused_decim = s.level_ds >= 1 && s.level_ds <= s.level_max;
+  // det-H of the top level by the launch that produces it (k_gauss.hip, TOP tiles); HESS_NO_TOP_FUSION=1: the round-4
+  // form (the level is stored, hessian_rows4_kernel reads it back) for A/B runs
+  const bool top_fused = s.level_max == g.dog + 1 && s.level_max >= 1 && !c->no_top_fusion;
+  c->zero_filled = false;
   // Level l of octave o from level l-1; the same launch emits det-H (+ gradient/theta) of level l-1 from the source
   // window it stages: 8 B R+W for the blur, 4 B (+8 B) W for the fused planes (+ 4 B per pixel of the next octave's
   // level 0 when it is the down-sampling level).
@@ -723,8 +729,20 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     j.norm_src = s.norm[l - 1];
     j.decim_dst = decim ? plane_ptr(gauss, o + 1, 0) : nullptr;
     j.decim_w = decim ? g.o[o + 1].wa : 0; j.decim_h = decim ? g.o[o + 1].h : 0;
+    if (top_fused && l == s.level_max) {
+      // The octave's top level is nobody's source: its det-H comes out of the launch that produces it (from the output
+      // tile in LDS) and the level itself is not written to HBM -- unless the parity tests ask (hess_debug_keep_levels).
+      j.deth_dst = plane_ptr(deth, o, l);
+      j.norm_dst = s.norm[l];
+      if (!c->keep_levels) j.dst = nullptr;
+      if (o == 0 && !user_mode) {  // octave 0's launch also clears what the detection stages expect zeroed
+        j.zero = c->zeroed.p;
+        j.zero_bytes = c->zeroed_used;
+      }
+    }
     return j;
   };
+  // (a fused top level reads its source and writes its own det-H instead of the level: the same 8 bytes)
   auto level_bytes = [&](int o, int l) {
     const OctGeom& og = g.o[o];
     const bool src_got = (l - 1 >= 1 && l - 1 <= g.dog);
@@ -732,8 +750,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     return (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)) + (decim ? (double)batch * g.o[o + 1].plane * 4.0 : 0.0);
   };
   auto launch_level = [&](const GaussJob& j) {
-    launch_gauss(st, j.src, nullptr, j.wa, (long long)j.wa * j.h, j.dst, j.wa, j.h, batch, j.taps, j.deth_src, j.got_src,
-                 j.norm_src, j.decim_dst, j.decim_w, j.decim_h);
+    if (j.zero) c->zero_filled = true;
+    launch_gauss_job(st, j, batch);
   };
   // T(o, l) = 3o + l is the earliest step of level l of octave o (level 0 of octave o+1 is the decimated level_ds of
   // octave o): the top level of an octave and level 1 of the next are due together and independent, so they share a
@@ -809,7 +827,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       if (l == 1 && deferred_o >= 0) {  // the previous octave's top level rides with this octave's level 1
         const GaussJob ja = level_job(deferred_o, s.level_max), jb = level_job(o, 1);
         ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max) + level_bytes(o, 1), deferred_o == 0 ? HESS_K_GAUSS_OCT0 : -1);
-        if (!launch_gauss_pair(st, ja, jb, batch)) { launch_level(ja); launch_level(jb); }
+        if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
+        else { launch_level(ja); launch_level(jb); }
         deferred_o = -1;
         continue;
       }
@@ -831,7 +850,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     ProfScope ps(c, HESS_K_GAUSS, top_bytes);
     // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves, from HBM: hessian_low_levels)
     LowLevels low{&g, gauss, deth, got, s.norm, chain_from, chained ? s.level_ds : 0};
-    if (!launch_gauss_multi(st, top_jobs, ntop, batch, &low)) {
+    if (launch_gauss_multi(st, top_jobs, ntop, batch, &low)) {
+      for (int k = 0; k < ntop; k++) c->zero_filled = c->zero_filled || top_jobs[k].zero != nullptr;
+    } else {
       for (int k = 0; k < ntop; k++) launch_level(top_jobs[k]);
       if (chained)  // (not reached with the schedules the chain is instantiated for)
         for (int o = chain_from; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, 0, s.level_ds - 1);
@@ -839,11 +860,12 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
-  {  // the octaves' top levels have no successor blur: one standalone launch for all of them
+  // (levels 0 .. level_max-1: by the launch that reads the level as its source; the top level: by the launch that
+  // produces it -- no launch here with the reference's level layout)
+  if (!top_fused) {  // the octaves' top levels from HBM, one launch for all of them
     double px = 0;
     for (int o = 0; o < g.noct; o++) px += g.o[o].plane;
     ProfScope ps(c, HESS_K_HESSIAN, (double)batch * px * 8.0);
-    c->zero_filled = false;
     if (s.level_max >= 1 && s.level_max <= g.dog) {  // (never with the reference's level layout: level_max = dog + 1)
       for (int o = 0; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, s.level_max, s.level_max);
     } else {
@@ -1593,6 +1615,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* m = getenv("HESS_MIRROR_MAX_BATCH")) c->mirror_max_batch = atoi(m);
   if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
   c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
+  c->no_top_fusion = getenv("HESS_NO_TOP_FUSION") != nullptr;
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
@@ -1965,6 +1988,10 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
     return HESS_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   const OctGeom& og = c->g.o[octave];
+  if (what == HESS_DBG_GAUSS && level == c->sch.level_max && !c->keep_levels && !c->no_top_fusion) {
+    set_err(c, "the top Gaussian level is not materialised: call hess_debug_keep_levels before the run");
+    return HESS_ERR_STATE;
+  }
   if (what == HESS_DBG_GAUSS || what == HESS_DBG_DETH) {
     const float* base = (const float*)(what == HESS_DBG_GAUSS ? c->gauss.p : c->deth.p);
     const float* src = base + og.lvl_off + ((long long)level * c->g.B + img) * og.plane;
@@ -1981,6 +2008,12 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
 }
 
 int hess_debug_regrown(hess_ctx* c) { return c ? c->regrown : HESS_ERR_ARG; }
+
+int hess_debug_keep_levels(hess_ctx* c, int on) {
+  if (!c) return HESS_ERR_ARG;
+  c->keep_levels = on != 0;
+  return 0;
+}
 
 int hess_share_results(hess_ctx* c, const char* name) {
   if (!c) return HESS_ERR_ARG;

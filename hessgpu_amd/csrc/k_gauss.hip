@@ -47,31 +47,60 @@ struct GaussArgs {
   // ProgramCU.cu:312-326: dst(x, y) = src(min(2x, w-1), 2y)); null unless this launch produces the down-sampling level
   float* decim_dst;  // [batch][dh][dw]
   int dw, dh;
+  // TOP tiles (the octave's top level, nobody's source inside the pyramid): det-Hessian of the PRODUCED level, computed
+  // from the output tile (+ a one-pixel halo) while it is in LDS -- the level itself is never written to HBM unless
+  // `dst` is given (hess_debug_keep_levels); norm_dst = sigma^4 of the produced level
+  float* deth_dst;
+  float norm_dst;
+  // ... and, on the side, the buffers the detection stages expect zeroed (no fill launch in the chain): 16-byte words
+  uint4* zero;
+  long long zero_n16;
   Taps taps;
 };
 
 __device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
 
-// LDS floats of one tile: (32 + 2R) staged rows of 64 + 2*R4 (+4 pad) columns
-template <int R>
-constexpr int gauss_tile_lds() { return (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4); }
+// LDS floats of one tile: (32 + 2R) staged rows of 64 + 2*R4 (+4 pad) columns; a TOP tile stages one more row above
+// and below and a column halo of R + 1 (its output tile has a one-pixel halo), and keeps the wrap-around columns of
+// the produced level behind the staged rows (2 x (34 + 2R) horizontally filtered values, 2 x 34 results)
+template <int R, bool TOP = false>
+constexpr int gauss_tile_lds() {
+  return TOP ? (TH + 2 * R + 2) * (TW + 2 * ((R + 1 + 3) & ~3) + 4) + ((2 * (TH + 2 + 2 * R) + 2 * (TH + 2) + 3) & ~3)
+             : (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4);
+}
 
 // One 64x32 tile of one level: the body of gauss_kernel, and of either half of gauss_pair_kernel.  `block` = the
 // workgroup's index among the launch's (or the half's) workgroups, `s` = gauss_tile_lds<R>() floats of LDS.
-template <int R, bool U8, bool HESS>
-__device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict__ s, const int block) {
+//
+// TOP (the octave's top level: nobody's source inside the pyramid, read again only to make its own det-Hessian): the
+// tile is produced with a one-pixel halo (66 x 34), kept in LDS, det-Hessian*sigma^4 of the PRODUCED level is computed
+// from it there and stored; the level itself goes to HBM only when a.dst is given (parity tests).  8 bytes per
+// octave-pixel of HBM traffic and the standalone det-H launch are gone.  The reference addresses det-H neighbours by
+// 1-D index (ProgramCU.cu:523-595): column -1 of a row is the LAST column of the row above, column w the FIRST of the
+// row below -- values of the far side of the image, which tiles at the left / right image border recompute for their
+// 34 rows with the same tap chains (a one-column horizontal + vertical pass from HBM: `wrap` below).
+template <int R, bool U8, bool HESS, bool TOP = false>
+__device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict__ s, const int block, const int nblocks = 0) {
   constexpr int FW = 2 * R + 1;
-  constexpr int R4 = (R + 3) & ~3;
+  constexpr int RTOP = TOP ? 1 : 0;    // halo of the output tile
+  constexpr int R4 = (R + RTOP + 3) & ~3;
   constexpr int OFF = R4 - R;
   constexpr int SW = TW + 2 * R4;
   constexpr int SWP = SW + 4;          // SW % 8 == 0 -> row stride = 4 (mod 8) dwords
-  constexpr int ROWS = TH + 2 * R;
+  constexpr int ROWS = TH + 2 * R + 2 * RTOP;
   constexpr int NG = SW / 4;           // 16-byte groups per staged row
   constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
-  static_assert(ROWS * SWP == gauss_tile_lds<R>(), "LDS size");
+  constexpr int NWH = TH + 2 + 2 * R;  // TOP: horizontally filtered values per wrap column
+  static_assert(ROWS * SWP + (TOP ? ((2 * NWH + 2 * (TH + 2) + 3) & ~3) : 0) == gauss_tile_lds<R, TOP>(), "LDS size");
+  static_assert(TW - 8 + 4 * NV <= SW, "register windows of the horizontal pass stay inside the staged row");
+  static_assert(!TOP || (!U8 && HESS), "a top level has a float source with fused planes");
 
   const int tid = threadIdx.x;
   const int w = a.w, h = a.h;
+  if (TOP && a.zero) {  // (block-uniform) the detection stages' zeroed buffers, a slice per workgroup; stores only
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = (long long)block * NT + tid; i < a.zero_n16; i += (long long)nblocks * NT) a.zero[i] = z;
+  }
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
   // XCD k takes the k-th contiguous eighth of the tile sequence (x fastest, then y, then image) and
   // neighbouring tiles -- which share halo rows/columns -- are served by the same 4 MiB L2.
@@ -96,7 +125,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     int g = it * NT + tid;
     g = g < ROWS * NG ? g : ROWS * NG - 1;  // surplus threads repeat the last group
     const int r = g / NG, gx = g - r * NG;
-    int y = y0 - R + r;
+    int y = y0 - R - RTOP + r;
     y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
     const int x = x0 - R4 + gx * 4;
     const int xs = x < 0 ? 0 : (x >= w ? w - 4 : x);  // w is a multiple of 4
@@ -131,6 +160,40 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
   }
   __syncthreads();
 
+  // ---- TOP, tiles at the left / right image border: the produced level at the far side of the image, for the 1-D
+  // neighbour addressing of det-H.  side 0 (left tiles): column w-1, rows y0-2 .. y0+31 (pixel (0, y) reads rows y-2,
+  // y-1, y of it); side 1 (right tiles): column 0, rows y0 .. y0+33 (pixel (w-1, y) reads rows y, y+1, y+2).  Same
+  // chains as the tile: v = fma(src(clamp(x - R + i)), k_i, v) along the row, then along the clamped rows. ----
+  float* const wrapH = s + ROWS * SWP;      // [2][NWH]
+  float* const wrapV = wrapH + 2 * NWH;     // [2][TH + 2]
+  const bool wrap_left = TOP && x0 == 0, wrap_right = TOP && x0 + TW >= w;  // block-uniform
+  if (TOP && (wrap_left || wrap_right)) {
+    const int side = tid >> 7, t = tid & 127;
+    const bool mine = side == 0 ? wrap_left : wrap_right;
+    static_assert(NWH <= 128 && NT == 256, "one thread per filtered row and side");
+    if (mine && t < NWH) {
+      int yy = (side == 0 ? y0 - 2 : y0) - R + t;
+      yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      const int c = side == 0 ? w - 1 : 0;
+      const float* row = a.src + img * a.src_img_stride + (long long)yy * a.src_pitch;
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < FW; i++) {
+        int xx = c - R + i;
+        xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+        v = fmaf(row[xx], a.taps.k[i], v);  // ProgramCU.cu:152
+      }
+      wrapH[side * NWH + t] = v;
+    }
+    __syncthreads();
+    if (mine && t < TH + 2) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < FW; i++) v = fmaf(wrapH[side * NWH + t + i], a.taps.k[i], v);  // ProgramCU.cu:226
+      wrapV[side * (TH + 2) + t] = v;
+    }
+  }
+
   // ---- stage 1b (HESS): det-Hessian*sigma^4 and (gradient, theta) of the SOURCE level for this tile,
   // straight from the staged source window: the level is never re-read from HBM for it
   // (ComputeHessian_Kernel, ProgramCU.cu:523-595).  A thread does 4 adjacent pixels in each of two rows 16 apart:
@@ -150,7 +213,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       if (gy < h && gx < w) {
         float U[6], M[6], D[6];  // columns gx-1 .. gx+4 of rows gy-1, gy, gy+1
         {
-          const float* base = &s[(hr + R - 1) * SWP + hx + R4];
+          const float* base = &s[(hr + R + RTOP - 1) * SWP + hx + R4];
 #pragma unroll
           for (int rr = 0; rr < 3; rr++) {
             float* dst = rr == 0 ? U : (rr == 1 ? M : D);
@@ -240,6 +303,14 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
         }
       }
     }
+    // TOP: the two halo columns of the output tile (image columns x0-1 and x0+64), one output per task
+    float hacc = 0.0f;
+    static_assert(2 * ROWS <= NT, "one halo task per thread");
+    if (TOP && tid < 2 * ROWS) {
+      const float* p = &s[(tid >> 1) * SWP + ((tid & 1) ? OFF + TW : OFF - 1)];
+#pragma unroll
+      for (int i = 0; i < FW; i++) hacc = fmaf(p[i], a.taps.k[i], hacc);  // ProgramCU.cu:152
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NTASK; k++) {
@@ -250,11 +321,12 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
         *reinterpret_cast<float4*>(&s[r * SWP + xb + 4]) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
       }
     }
+    if (TOP && tid < 2 * ROWS) s[(tid >> 1) * SWP + TW + (tid & 1)] = hacc;  // columns 64 (left halo), 65 (right halo) of the row
   }
   __syncthreads();
 
   // ---- stage 3: vertical pass, LDS -> HBM ----
-  {
+  if (!TOP) {
     const int cg = tid & 31, rg = tid >> 5;
     float2 col[4 + 2 * R];
 #pragma unroll
@@ -295,6 +367,117 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       }
     }
   }
+  if (TOP) {
+    // ---- stage 3 (TOP): vertical pass over the tile and its halo, LDS -> registers -> LDS.  Column pairs 0..31 are the
+    // tile's, pair 32 = the two halo columns (row entries 64, 65); row groups of four start at tile rows -1, 3, .. 27
+    // and 29 (the last one recomputes rows 29, 30: same values). ----
+    constexpr int NCP = TW / 2 + 1, NRG = TH / 4 + 1, NTV = NCP * NRG, KV = (NTV + NT - 1) / NT;
+    constexpr int TS = TW + 8;  // row pitch of the output tile in LDS: image column x0 - 4 + c, tile row -1 + r
+    static_assert((TH + 2) * TS <= ROWS * SWP, "the output tile reuses the staged rows' LDS");
+    float2 vout[KV][4];
+    int vr0[KV], vcp[KV];
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      const int t = tid + k * NT;
+      const int rgi = t / NCP;
+      vcp[k] = t - rgi * NCP;
+      vr0[k] = t < NTV ? (rgi < TH / 4 ? 4 * rgi - 1 : TH - 3) : -100;
+      if (t < NTV) {
+        float2 col[4 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * R; i++)
+          col[i] = *reinterpret_cast<const float2*>(&s[(vr0[k] + 1 + i) * SWP + vcp[k] * 2]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) vout[k][j] = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int i = 0; i < FW; i++) {
+          const float ki = a.taps.k[i];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            vout[k][j].x = fmaf(col[j + i].x, ki, vout[k][j].x);  // ProgramCU.cu:226
+            vout[k][j].y = fmaf(col[j + i].y, ki, vout[k][j].y);
+          }
+        }
+      }
+    }
+    __syncthreads();  // every column of horizontal results has been read: the output tile takes their place
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      if (vr0[k] > -100) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float* trow = &s[(vr0[k] + 1 + j) * TS];
+          if (vcp[k] < TW / 2) *reinterpret_cast<float2*>(&trow[4 + 2 * vcp[k]]) = vout[k][j];
+          else { trow[3] = vout[k][j].x; trow[4 + TW] = vout[k][j].y; }
+        }
+        if (a.dst && vcp[k] < TW / 2) {  // (block-uniform pointer) the level itself, only on request
+          const int x = x0 + 2 * vcp[k];
+          float* d = a.dst + img * (long long)w * h;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int ty = vr0[k] + j, y = y0 + ty;
+            if (ty >= 0 && ty < TH && y < h && x < w) *reinterpret_cast<float2*>(&d[(long long)y * w + x]) = vout[k][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- stage 4 (TOP): det-Hessian*sigma^4 of the produced level from the output tile (ComputeHessian_Kernel,
+    // ProgramCU.cu:523-553; thread -> pixels as stage 1b) ----
+    {
+      const int hx = (tid & 15) * 4;
+      const int gx = x0 + hx;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int hr = (tid >> 4) + 16 * half;
+        const int gy = y0 + hr;
+        if (gy < h && gx < w) {
+          float U[6], M[6], D[6];  // columns gx-1 .. gx+4 of rows gy-1, gy, gy+1
+          {
+            const float* base = &s[hr * TS + hx + 4];  // tile row hr-1, image column gx
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) {
+              float* dst = rr == 0 ? U : (rr == 1 ? M : D);
+              const float4 v = *reinterpret_cast<const float4*>(base + rr * TS);
+              dst[0] = base[rr * TS - 1];
+              dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
+              dst[5] = base[rr * TS + 4];
+            }
+          }
+          // 1-D neighbour addressing: rows outside the plane read 0, column -1 / w is the adjacent row's far end
+          if (gy == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) U[j] = 0.0f;
+          }
+          if (gy == h - 1) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) D[j] = 0.0f;
+          }
+          if (gx == 0) {  // index - w - 1, index - 1, index + w - 1: column w-1 of rows gy-2, gy-1, gy
+            U[0] = gy >= 2 ? wrapV[hr] : 0.0f; M[0] = gy >= 1 ? wrapV[hr + 1] : 0.0f; D[0] = wrapV[hr + 2];
+          }
+          if (gx + 4 == w) {  // index - w + 1, index + 1, index + w + 1 of the row's last pixel: column 0 of rows gy, gy+1, gy+2
+            U[5] = wrapV[TH + 2 + hr]; M[5] = gy + 1 <= h - 1 ? wrapV[TH + 2 + hr + 1] : 0.0f; D[5] = gy + 2 <= h - 1 ? wrapV[TH + 2 + hr + 2] : 0.0f;
+          }
+          float hv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+#define HESS_V2(A, K) ((v2f){A[(K)], A[(K) + 1]})
+            const v2f v11 = HESS_V2(U, j), v12 = HESS_V2(U, j + 1), v13 = HESS_V2(U, j + 2);
+            const v2f v21 = HESS_V2(M, j), v22 = HESS_V2(M, j + 1), v23 = HESS_V2(M, j + 2);
+            const v2f v31 = HESS_V2(D, j), v32 = HESS_V2(D, j + 1), v33 = HESS_V2(D, j + 2);
+#undef HESS_V2
+            const v2f Lxx = v2_fma(v2_splat(-2.0f), v22, v21) + v23;   // ProgramCU.cu:536
+            const v2f Lyy = v2_fma(v2_splat(-2.0f), v22, v12) + v32;   // :537
+            const v2f Lxy = (v13 - v11 + v31 - v33) * v2_splat(0.25f);  // :538
+            const v2f dh = v2_fma(Lxx, Lyy, -(Lxy * Lxy)) * v2_splat(a.norm_dst);  // :553
+            hv[j] = dh.x; hv[j + 1] = dh.y;
+          }
+          store_stream_f4(a.deth_dst + img * (long long)w * h + (long long)gy * w + gx, hv[0], hv[1], hv[2], hv[3]);
+        }
+      }
+    }
+  }
 }
 
 template <int R, bool U8, bool HESS>
@@ -303,15 +486,23 @@ __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   gauss_tile<R, U8, HESS>(a, s, (int)blockIdx.x);
 }
 
+// The octave's top level: det-H of the produced level from the output tile, the level itself not stored (gauss_tile, TOP).
+template <int R>
+__global__ __launch_bounds__(NT) void gauss_top_kernel(GaussArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R, true>()];
+  gauss_tile<R, false, true, true>(a, s, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // Two level launches that do not depend on each other in one grid: the top level of octave o (taps RA, its source level
 // has a gradient plane) and level 1 of octave o+1 (taps RB) -- T(o, l) = 3o + l is the earliest step of level l of
 // octave o, so level 4 of one octave and level 1 of the next are due together.  The small half hides behind the large
 // one: six launches fewer in the dependent chain of a 1080p pyramid.  The first blocks_a workgroups do half a.
+// Half a is a TOP tile (gauss_tile): det-H of the top level from its output tile, the level itself not stored.
 template <int RA, int RB>
 __global__ __launch_bounds__(NT) void gauss_pair_kernel(GaussArgs a, GaussArgs b, int blocks_a) {
-  constexpr int LDS = gauss_tile_lds<RA>() > gauss_tile_lds<RB>() ? gauss_tile_lds<RA>() : gauss_tile_lds<RB>();
+  constexpr int LDS = gauss_tile_lds<RA, true>() > gauss_tile_lds<RB>() ? gauss_tile_lds<RA, true>() : gauss_tile_lds<RB>();
   __shared__ __attribute__((aligned(16))) float s[LDS];
-  if ((int)blockIdx.x < blocks_a) gauss_tile<RA, false, true>(a, s, (int)blockIdx.x);  // (workgroup-uniform)
+  if ((int)blockIdx.x < blocks_a) gauss_tile<RA, false, true, true>(a, s, (int)blockIdx.x, blocks_a);  // (workgroup-uniform)
   else gauss_tile<RB, false, true>(b, s, (int)blockIdx.x - blocks_a);
 }
 
@@ -558,7 +749,7 @@ struct MultiArgs {
 struct MultiGeom { Geom g; };
 template <int R>
 __global__ __launch_bounds__(NT) void gauss_multi_kernel(MultiArgs m, MultiGeom mg) {
-  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R>()];
+  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R, true>()];
   const int blk = (int)blockIdx.x;
   if (blk >= m.first_block[m.njobs]) {  // (workgroup-uniform)
     const int lb = blk - m.first_block[m.njobs];
@@ -568,7 +759,7 @@ __global__ __launch_bounds__(NT) void gauss_multi_kernel(MultiArgs m, MultiGeom 
   }
   int k = 0;
   for (int q = 1; q < m.njobs; q++) if (blk >= m.first_block[q]) k = q;  // (uniform scalar walk)
-  gauss_tile<R, false, true>(m.j[k], s, blk - m.first_block[k]);
+  gauss_tile<R, false, true, true>(m.j[k], s, blk - m.first_block[k], m.first_block[k + 1] - m.first_block[k]);  // top levels: TOP tiles
 }
 
 template <int R>
@@ -578,7 +769,9 @@ void launch_r(hipStream_t st, GaussArgs a, int batch) {
   a.batch = batch;
   const int ntile = a.tiles_x * a.tiles_y * batch;
   dim3 grid(((ntile + 7) / 8) * 8);
-  if (a.src_u8)
+  if (a.deth_dst)
+    hipLaunchKernelGGL((gauss_top_kernel<R>), grid, dim3(NT), 0, st, a);
+  else if (a.src_u8)
     hipLaunchKernelGGL((gauss_kernel<R, true, false>), grid, dim3(NT), 0, st, a);
   else if (a.deth_src)
     hipLaunchKernelGGL((gauss_kernel<R, false, true>), grid, dim3(NT), 0, st, a);
@@ -678,6 +871,8 @@ __global__ __launch_bounds__(256) void downsample_kernel(const float* src, int s
 
 }  // namespace
 
+namespace { void launch_by_radius(hipStream_t st, const GaussArgs& a, int batch); }
+
 void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long long src_pitch,
                   long long src_img_stride, float* dst, int wa, int h, int batch, const Taps& taps,
                   float* deth_src, float* got_src, float norm_src, float* decim_dst, int decim_w, int decim_h) {
@@ -686,7 +881,13 @@ void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long 
   a.src = src; a.src_u8 = src_u8; a.src_pitch = src_pitch; a.src_img_stride = src_img_stride;
   a.dst = dst; a.w = wa; a.h = h; a.taps = taps;
   a.deth_src = deth_src; a.got_src = reinterpret_cast<float2*>(got_src); a.norm_src = norm_src;
-  switch (taps.fw >> 1) {
+  a.deth_dst = nullptr; a.norm_dst = 0.0f; a.zero = nullptr; a.zero_n16 = 0;
+  launch_by_radius(st, a, batch);
+}
+
+namespace {
+void launch_by_radius(hipStream_t st, const GaussArgs& a, int batch) {
+  switch (a.taps.fw >> 1) {
     case 2: launch_r<2>(st, a, batch); break;
     case 3: launch_r<3>(st, a, batch); break;
     case 4: launch_r<4>(st, a, batch); break;
@@ -705,7 +906,7 @@ void launch_gauss(hipStream_t st, const float* src, const uint8_t* src_u8, long 
     default: break;
   }
 }
-
+}  // namespace
 
 namespace {
 GaussArgs job_args(const GaussJob& j, int batch) {
@@ -714,6 +915,8 @@ GaussArgs job_args(const GaussJob& j, int batch) {
   a.src = j.src; a.src_u8 = nullptr; a.src_pitch = j.wa; a.src_img_stride = (long long)j.wa * j.h;
   a.dst = j.dst; a.w = j.wa; a.h = j.h; a.taps = j.taps;
   a.deth_src = j.deth_src; a.got_src = reinterpret_cast<float2*>(j.got_src); a.norm_src = j.norm_src;
+  a.deth_dst = j.deth_dst; a.norm_dst = j.norm_dst;
+  a.zero = reinterpret_cast<uint4*>(j.zero); a.zero_n16 = (long long)(j.zero_bytes / 16);
   a.tiles_x = (j.wa + TW - 1) / TW; a.tiles_y = (j.h + TH - 1) / TH; a.batch = batch;
   return a;
 }
@@ -733,11 +936,16 @@ bool launch_pair_b(hipStream_t st, const GaussArgs& a, const GaussArgs& b, int r
 }
 }  // namespace
 
+// One level launch described by a job (any level; a job with deth_dst is a top level: TOP tiles).
+void launch_gauss_job(hipStream_t st, const GaussJob& j, int batch) {
+  launch_by_radius(st, job_args(j, batch), batch);
+}
+
 // Level launches a (the larger: top level of an octave) and b (level 1 of the next octave) in one grid.  Instantiated
 // for the tap counts around the reference's default schedule (a: 17-25 taps, b: 9-13); false = not this pair, launch
 // them one after the other.
 bool launch_gauss_pair(hipStream_t st, const GaussJob& ja, const GaussJob& jb, int batch) {
-  if (!ja.deth_src || !jb.deth_src) return false;
+  if (!ja.deth_src || !jb.deth_src || !ja.deth_dst || jb.deth_dst) return false;  // a: a top level (TOP tile), b: not
   const GaussArgs a = job_args(ja, batch), b = job_args(jb, batch);
   const int rb = jb.taps.fw >> 1;
   switch (ja.taps.fw >> 1) {
@@ -780,7 +988,7 @@ bool launch_gauss_multi(hipStream_t st, const GaussJob* jobs, int njobs, int bat
   const int r = jobs[0].taps.fw >> 1;
   if (r < 8 || r > 12) return false;
   for (int k = 0; k < njobs; k++)
-    if (!jobs[k].deth_src || !jobs[k].got_src || (jobs[k].taps.fw >> 1) != r) return false;
+    if (!jobs[k].deth_src || !jobs[k].got_src || !jobs[k].deth_dst || (jobs[k].taps.fw >> 1) != r) return false;
   for (int k0 = 0; k0 < njobs; k0 += kMultiJobs) {
     MultiArgs m;
     MultiGeom mg;

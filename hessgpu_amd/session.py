@@ -191,6 +191,12 @@ class Session:
         self._check(self._f["device_results"](self._h, C.byref(k), C.byref(d), C.byref(cap)))
         return k.value, d.value, cap.value
 
+    def keep_levels(self, on=True):
+        """Product: also store the top Gaussian level of every octave (never materialised by default) so that
+        level(..., DBG_GAUSS) can return it; the oracle keeps all levels anyway (hess_cpu_keep_levels)."""
+        if "debug_keep_levels" in self._f:
+            self._check(self._f["debug_keep_levels"](self._h, int(on)))
+
     def regrown(self):
         """Times the context grew its feature storage after an overflow and ran the batch again (product only)."""
         return self._check(self._f["debug_regrown"](self._h))

@@ -225,6 +225,11 @@ int hess_debug_key_levels(hess_ctx* ctx, const int* levels, int num);
  * again (the reference grows its lists per image, PyramidCU.cpp:393-397).  The environment variable
  * HESS_INITIAL_CAP=<n> makes a new context start with room for n detections per image so that tests can force it. */
 int hess_debug_regrown(hess_ctx* ctx);
+/* Parity hook: the top Gaussian level of every octave (level dog+1) is nobody's input -- the launch that produces it
+ * computes its det-Hessian from the output tile and does NOT write the level to HBM (the reference materialises it,
+ * PyramidCU.cpp:1486-1558, and reads it back once, :1576-1591).  on != 0: the following runs of this context store it
+ * as well, so that hess_debug_level(HESS_DBG_GAUSS, level dog+1) can return it (HESS_ERR_STATE otherwise). */
+int hess_debug_keep_levels(hess_ctx* ctx, int on);
 
 /* Multi-process jobs on one node (one process per GPU): keep this context's pinned host result buffers in
  * POSIX shared memory so that another process of the node -- the rank that collects the global batch -- reads them in

@@ -88,3 +88,42 @@ def test_failed_upload_never_runs_the_kernels_on_garbage():
 
 def test_invalid_copy_engine_falls_back():
     _child({"HESS_COPIER_ENGINE": "0x80000000"}, False, "")
+
+
+CHILD_POISONED = r"""
+import sys
+sys.path[:0] = [{root!r}, {root!r} + "/tests"]
+import numpy as np
+import fixtures, hessgpu_amd
+
+lum = np.ascontiguousarray(fixtures.load_rgb("640-1.jpg")[..., 1])
+batch = np.stack([lum, lum[::-1].copy(), lum[:, ::-1].copy(), lum])
+g = hessgpu_amd.HessContext(0)
+try:
+    g.run(batch)
+except hessgpu_amd.HessError as e:
+    assert e.code == -3 and "did not complete in time" in str(e), str(e)
+else:
+    raise SystemExit("the injected fault did not fail the batch")
+for call in (lambda: g.run(batch), lambda: g.reserve(lum.shape[1], lum.shape[0], 4), lambda: g.run(batch[:1])):
+    try:
+        call()
+    except hessgpu_amd.HessError as e:
+        assert e.code == -3 and "poisoned" in str(e), str(e)
+    else:
+        raise SystemExit("a poisoned context accepted another run")
+g.close()            # leaves the copy's buffers and signals alone (they may still be written); must not crash
+g2 = hessgpu_amd.HessContext(0)   # a new context of the same process works
+n = g2.run(batch)
+assert min(n) > 100, n
+g2.close()
+print("CHILD OK")
+"""
+
+
+def test_a_really_lost_copy_poisons_the_context():
+    """after a REAL timeout the copy may still be in flight: the context must neither reuse nor free its
+    targets.  HESS_COPIER_FAULT=poisoned reports the first wait as a real timeout (the copy has in fact completed)."""
+    env = dict(os.environ, HESS_COPIER_FAULT="poisoned", HESS_DELIVERY="dma")
+    r = subprocess.run([sys.executable, "-c", CHILD_POISONED.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHILD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

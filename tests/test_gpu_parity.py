@@ -55,6 +55,7 @@ def _assert_same_features(gk, gd, ok, od, what):
 
 
 def _compare_all(g, o, imgs, what, stages=True):
+    g.keep_levels(stages)   # the top Gaussian level of an octave is only written to HBM on request (hess_debug_keep_levels)
     ng = g.run(imgs)
     no = o.run(imgs)
     assert g.geometry() == o.geometry()

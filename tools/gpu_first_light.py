@@ -57,7 +57,8 @@ main()
 def orient_debug():
     name = sys.argv[1] if len(sys.argv) > 1 else "640-1.jpg"
     img = fixtures.load_rgb(name)
-    g = hessgpu_amd.HessContext(0); o = OracleSession(threads=8)
+    g = hessgpu_amd.HessContext(0)
+    g.keep_levels(True); o = OracleSession(threads=8)
     g.run(img[None]); o.run(img[None])
     gk, _ = g.fetch(0); ok, _ = o.fetch(0)
     from collections import OrderedDict
