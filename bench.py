@@ -79,6 +79,8 @@ def main():
                          "also in host memory, read in place from the node-shared pinned buffers every rank's own "
                          "copier delivers into (each GPU over its own host link); host = rank 0 copies the gathered "
                          "lists from its HBM to pinned memory through its own link; hbm = in rank 0's HBM only")
+    ap.add_argument("--desc-order", type=int, default=-1, help="descriptor summation order (include/hess_abi.h HESS_DESC_ORDER_*: 0 interleaved, "
+                    "1 sequential = the reference's, 2 pixel raster); default: what hess_default_params chooses")
     ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "
                     "the headline workload uses the default (all 7 octaves of 1920x1080)")
     args = ap.parse_args()
@@ -147,9 +149,10 @@ def main():
     # Contexts used round-robin: while one batch's results travel to the host (and, for N > 1, are gathered over
     # RCCL), the next batches' kernels already run on the other contexts' streams.
     nctx = max(1, args.contexts)
+    order_kw = {"descriptor_order": args.desc_order} if args.desc_order >= 0 else {}
     def make_contexts():
         return [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
-                                        octave_num=args.octaves) for _ in range(nctx)]
+                                        octave_num=args.octaves, **order_kw) for _ in range(nctx)]
 
     ctxs = make_contexts()
     desc_order = int(ctxs[0].params.descriptor_order)   # hess_default_params' choice (include/hess_abi.h, HESS_DESC_ORDER_*)
@@ -336,7 +339,7 @@ def main():
         saved = os.environ.get("HESS_DELIVERY")
         os.environ["HESS_DELIVERY"] = "dma" if _mirror_is_default(B) else "mirror"   # the other form
         cd = hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
-                                     octave_num=args.octaves)
+                                     octave_num=args.octaves, **order_kw)
         if saved is None:
             del os.environ["HESS_DELIVERY"]
         else:

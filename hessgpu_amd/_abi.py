@@ -19,7 +19,7 @@ HESS_ERR_UNSUPPORTED = -6
 
 TYPE_DARK_BLOB, TYPE_BRIGHT_BLOB, TYPE_SADDLE, TYPE_NONE = 0, 1, 2, 3
 TRUNC_HIGHEST_0, TRUNC_HIGHEST_1, TRUNC_LOWEST, TRUNC_TOPK = 0, 1, 2, 3
-DESC_ORDER_INTERLEAVED, DESC_ORDER_SEQUENTIAL = 0, 1
+DESC_ORDER_INTERLEAVED, DESC_ORDER_SEQUENTIAL, DESC_ORDER_PIXEL = 0, 1, 2
 FMT_LUM, FMT_LUM_ALPHA, FMT_RGB, FMT_RGBA, FMT_BGR, FMT_BGRA = 1, 2, 3, 4, 5, 6
 PIX_U8, PIX_U16, PIX_F32 = 1, 2, 3
 DBG_GAUSS, DBG_DETH, DBG_GOT = 0, 1, 2

@@ -136,6 +136,7 @@ struct DescParams {
   int first_image;       // the launch covers images first_image .. first_image + gridDim.y - 1 of the batch
   int xcd_block;         // features per block of the list handed to one XCD's workgroups (0: plain order)
   int sequential;        // HESS_DESC_ORDER_SEQUENTIAL: bins summed in the reference's sample order (else four interleaved partial sums)
+  int pixel;             // HESS_DESC_ORDER_PIXEL: one raster over the footprint, fixed-point sums (descriptor_pixel_kernel); wins over `sequential`
 };
 
 // ---- launchers (each enqueues on `st`, no host synchronisation) ----------------------------

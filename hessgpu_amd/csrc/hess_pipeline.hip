@@ -958,6 +958,9 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.first_image = 0;
   dsp.xcd_block = c->desc_xcd_block;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
+  // the pixel order's fixed point assumes luminance in [0, 1] (8- and 16-bit inputs); float pixels are taken as they are
+  // and keep the interleaved order (oracle/hess_oracle.c: the same rule)
+  dsp.pixel = p.descriptor_order == HESS_DESC_ORDER_PIXEL && pixtype != HESS_PIX_F32;
   // Delivered by the copier thread, a batch of four or more images gets its descriptors in two launches (the images
   // are independent and packed back to back): the first half's results cross the host link while the second half is
   // computed -- half of the transfer (0.53 ms for eight 1080p images) leaves the batch's critical path.  Four groups
@@ -1096,6 +1099,7 @@ int enqueue_user(hess_ctx* c) {
   dsp.first_image = 0;
   dsp.xcd_block = c->desc_xcd_block;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
+  dsp.pixel = 0;  // a keypoint list is described in a floating-point order (interleaved unless the sequential one is asked for)
   c->nparts = 1;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
@@ -1581,7 +1585,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   for (int r : c->p.reserved) reserved_nonzero = reserved_nonzero || r != 0;
   if (c->p.abi_version == 2 && c->p.descriptor_order == 0) c->p.abi_version = HESS_ABI_VERSION;  // a version-2 struct: same layout, the new word zero
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
-      c->p.descriptor_order < 0 || c->p.descriptor_order > HESS_DESC_ORDER_SEQUENTIAL || reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
+      c->p.descriptor_order < 0 || c->p.descriptor_order > HESS_DESC_ORDER_PIXEL || reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);
     delete c;
     return nullptr;

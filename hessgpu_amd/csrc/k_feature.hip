@@ -460,6 +460,91 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
   acc = fmaf(coef, wb, acc);
 }
 
+// Host keypoint records (PyramidCU.cpp:866-906 / :1097-1137, host arithmetic) of one image, by the whole workgroup: one
+// thread per feature, 256 per pass, staged in LDS (`kst`: 256 x 24 bytes, not otherwise in use yet) and stored as
+// contiguous 8-byte pieces -- 24-byte records stored one by one from a lane of every wavefront reached the pinned host
+// mirror as as many small PCIe writes and cost the kernel as much as the 512-byte descriptors did.
+// (by the launch's LAST workgroups: the first ones hold the largest features and are the launch's critical path)
+template <bool HOST_MIRROR>
+__device__ __forceinline__ void keypoint_records(const DescParams& dp, uint32_t* const kst, const RawKey* list, int cap_list,
+                                                 const FRec* recs, const int* fsrc, int cap_feat, int b, int ftotal, int ffirst,
+                                                 long long obase, HostKeypoint* keys) {
+  for (int f0 = (gridDim.x - 1 - blockIdx.x) * 256; f0 < ftotal; f0 += gridDim.x * 256) {  // (uniform over the workgroup)
+    const int nrec = min(256, ftotal - f0);
+    if ((int)threadIdx.x < nrec) {
+      const int m = ffirst + f0 + threadIdx.x;
+      const int src = fsrc[(long long)b * cap_feat + m];
+      const int i = src >> 2, k = src & 3;
+      const FRec rec = recs[(long long)b * cap_list + i];
+      const int li = list[(long long)b * cap_list + i].level_index;
+      const float kw = dp.multi ? (float)((2.0 * kPI / 255.0) * (double)((rec.w >> (8 * k)) & 0xFFu))
+                                : __uint_as_float(rec.w);
+      const float kx = (float)(rec.x & 0x00FFFFFFu) / 1024.0f;
+      const float ky = (float)(rec.y & 0x00FFFFFFu) / 1024.0f;
+      const float kz = (float)(rec.z & 0x0000FFFFu) / 256.0f;
+      const float oss = dp.octave_sigma * (float)(1 << (li / dp.dog));
+      const float offset = dp.lowe_origin ? 0.0f : 0.5f;
+      HostKeypoint hk;
+      hk.x = __fadd_rn(__fmul_rn(oss, kx - 0.5f), offset);
+      hk.y = __fadd_rn(__fmul_rn(oss, ky - 0.5f), offset);
+      hk.s = oss * kz;
+      hk.o = (float)fmod(2.0 * kPI - (double)kw, 2.0 * kPI);
+      hk.response = dm_h2f(((rec.x & 0xFF000000u) >> 16) | ((rec.y & 0xFF000000u) >> 24));
+      hk.level = (uint16_t)li;
+      hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
+      *reinterpret_cast<HostKeypoint*>(kst + 6 * threadIdx.x) = hk;
+    }
+    __syncthreads();
+    const uint2* const k2 = reinterpret_cast<const uint2*>(kst);
+    uint2* const out = reinterpret_cast<uint2*>(keys + obase + f0);
+    uint2* const hout = (HOST_MIRROR && dp.hkeys) ? reinterpret_cast<uint2*>(dp.hkeys + obase + f0) : nullptr;
+    for (int j = threadIdx.x; j < 3 * nrec; j += 256) {
+      const uint2 v = k2[j];
+      out[j] = v;
+      if (hout) hout[j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// Normalisation with the reference's 32-lane tree (NormalizeDescriptor_Kernel + ND_WarpReduction, ProgramCU.cu:1950-2054)
+// and the 512-byte (256-byte) coalesced store of one descriptor; lanes 0..31 hold four (two) consecutive values each.
+template <bool HOST_MIRROR>
+__device__ __forceinline__ void finish_descriptor128(const DescParams& dp, int lane, float4 v, float* dout, float* hout) {
+  if (dp.normalize) {
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      float part = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d);
+      const float nrm = 1.0f / sqrtf(rl(part, 0));
+      if (pass == 0) {
+        v.x = fminf(0.2f, v.x * nrm); v.y = fminf(0.2f, v.y * nrm);
+        v.z = fminf(0.2f, v.z * nrm); v.w = fminf(0.2f, v.w * nrm);
+      } else { v.x *= nrm; v.y *= nrm; v.z *= nrm; v.w *= nrm; }
+    }
+  }
+  if (lane < 32) *reinterpret_cast<float4*>(dout + lane * 4) = v;
+  // (streaming stores for the mirror were measured: 0.341 - 0.346 against 0.333 - 0.339 ms per single image, same call)
+  if (HOST_MIRROR && hout && lane < 32) *reinterpret_cast<float4*>(hout + lane * 4) = v;
+}
+template <bool HOST_MIRROR>
+__device__ __forceinline__ void finish_descriptor64(const DescParams& dp, int lane, float2 v, float* dout, float* hout) {
+  if (dp.normalize) {
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      float part = fmaf(v.y, v.y, v.x * v.x);
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d);
+      const float nrm = 1.0f / sqrtf(rl(part, 0));
+      if (pass == 0) { v.x = fminf(0.2f, v.x * nrm); v.y = fminf(0.2f, v.y * nrm); }
+      else { v.x *= nrm; v.y *= nrm; }
+    }
+  }
+  if (lane < 32) *reinterpret_cast<float2*>(dout + lane * 2) = v;
+  if (HOST_MIRROR && hout && lane < 32) *reinterpret_cast<float2*>(hout + lane * 2) = v;
+}
+
 // One wavefront per feature.  Lane = cell*4 + sub.
 //   scan   the four lanes of a cell take four consecutive samples of the cell's box per iteration (scan order of
 //          ProgramCU.cu:1723-1774: y outer, x inner), so the 16 cells advance together; a lane steps its own
@@ -498,49 +583,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   const int mycell = lane >> 2, sub = lane & 3;
   float* const rows = &crow[wv][0];
 
-  // Host keypoint records (PyramidCU.cpp:866-906 / :1097-1137, host arithmetic): one thread per feature, 256 per
-  // workgroup, staged in LDS (the coefficient tables are not in use yet) and stored as contiguous 8-byte pieces --
-  // 24-byte records stored one by one from a lane of every wavefront reached the pinned host mirror as as many
-  // small PCIe writes and cost the kernel as much as the 512-byte descriptors did.
-  // (by the launch's LAST workgroups: the first ones hold the largest features and are the launch's critical path)
-  for (int f0 = (gridDim.x - 1 - blockIdx.x) * 256; f0 < ftotal; f0 += gridDim.x * 256) {  // (uniform over the workgroup)
-    const int nrec = min(256, ftotal - f0);
-    uint32_t* const kst = reinterpret_cast<uint32_t*>(&crow[0][0]);
-    static_assert(sizeof(HostKeypoint) == 24 && 4 * DC_ROWS * 4 >= 256 * 24, "record staging fits the table");
-    if ((int)threadIdx.x < nrec) {
-      const int m = ffirst + f0 + threadIdx.x;
-      const int src = fsrc[(long long)b * cap_feat + m];
-      const int i = src >> 2, k = src & 3;
-      const FRec rec = recs[(long long)b * cap_list + i];
-      const int li = list[(long long)b * cap_list + i].level_index;
-      const float kw = dp.multi ? (float)((2.0 * kPI / 255.0) * (double)((rec.w >> (8 * k)) & 0xFFu))
-                                : __uint_as_float(rec.w);
-      const float kx = (float)(rec.x & 0x00FFFFFFu) / 1024.0f;
-      const float ky = (float)(rec.y & 0x00FFFFFFu) / 1024.0f;
-      const float kz = (float)(rec.z & 0x0000FFFFu) / 256.0f;
-      const float oss = dp.octave_sigma * (float)(1 << (li / dp.dog));
-      const float offset = dp.lowe_origin ? 0.0f : 0.5f;
-      HostKeypoint hk;
-      hk.x = __fadd_rn(__fmul_rn(oss, kx - 0.5f), offset);
-      hk.y = __fadd_rn(__fmul_rn(oss, ky - 0.5f), offset);
-      hk.s = oss * kz;
-      hk.o = (float)fmod(2.0 * kPI - (double)kw, 2.0 * kPI);
-      hk.response = dm_h2f(((rec.x & 0xFF000000u) >> 16) | ((rec.y & 0xFF000000u) >> 24));
-      hk.level = (uint16_t)li;
-      hk.type = (uint16_t)((rec.z & 0xC0000000u) >> 30);
-      *reinterpret_cast<HostKeypoint*>(kst + 6 * threadIdx.x) = hk;
-    }
-    __syncthreads();
-    const uint2* const k2 = reinterpret_cast<const uint2*>(kst);
-    uint2* const out = reinterpret_cast<uint2*>(keys + obase + f0);
-    uint2* const hout = (HOST_MIRROR && dp.hkeys) ? reinterpret_cast<uint2*>(dp.hkeys + obase + f0) : nullptr;
-    for (int j = threadIdx.x; j < 3 * nrec; j += 256) {
-      const uint2 v = k2[j];
-      out[j] = v;
-      if (hout) hout[j] = v;
-    }
-    __syncthreads();
-  }
+  static_assert(sizeof(HostKeypoint) == 24 && 4 * DC_ROWS * 4 >= 256 * 24, "record staging fits the table");
+  keypoint_records<HOST_MIRROR>(dp, reinterpret_cast<uint32_t*>(&crow[0][0]), list, cap_list, recs, fsrc, cap_feat, b, ftotal, ffirst, obase, keys);
   if (!desc) return;
   for (int i = lane; i < DC_ROWS; i += 64) rows[i] = 0.0f;
   float* const mycol = rows + mycell * 4 + sub;  // + DC_BIN_PITCH*bin: the column this lane fills (cell, slot `sub`)
@@ -767,42 +811,255 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
     // same wavefront wrote dl[wv]; LDS operations of one wavefront complete in order
     __builtin_amdgcn_wave_barrier();
     float* dout = desc + (obase + oidx) * dim;
+    float* hout = (HOST_MIRROR && dp.hdesc) ? dp.hdesc + (obase + oidx) * dim : nullptr;
     if (dp.half_sift) {
       float2 v = make_float2(0, 0);
       if (lane < 32) v = *reinterpret_cast<const float2*>(&dl[wv][lane * 2]);
-      if (dp.normalize) {
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-          float part = fmaf(v.y, v.y, v.x * v.x);
-#pragma unroll
-          for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d);
-          const float nrm = 1.0f / sqrtf(rl(part, 0));
-          if (pass == 0) { v.x = fminf(0.2f, v.x * nrm); v.y = fminf(0.2f, v.y * nrm); }
-          else { v.x *= nrm; v.y *= nrm; }
-        }
-      }
-      if (lane < 32) *reinterpret_cast<float2*>(dout + lane * 2) = v;
-      if (HOST_MIRROR && dp.hdesc && lane < 32) *reinterpret_cast<float2*>(dp.hdesc + (obase + oidx) * dim + lane * 2) = v;
+      finish_descriptor64<HOST_MIRROR>(dp, lane, v, dout, hout);
     } else {
       float4 v = make_float4(0, 0, 0, 0);
       if (lane < 32) v = *reinterpret_cast<const float4*>(&dl[wv][lane * 4]);
-      if (dp.normalize) {
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-          float part = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
-#pragma unroll
-          for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d);
-          const float nrm = 1.0f / sqrtf(rl(part, 0));
-          if (pass == 0) {
-            v.x = fminf(0.2f, v.x * nrm); v.y = fminf(0.2f, v.y * nrm);
-            v.z = fminf(0.2f, v.z * nrm); v.w = fminf(0.2f, v.w * nrm);
-          } else { v.x *= nrm; v.y *= nrm; v.z *= nrm; v.w *= nrm; }
-        }
-      }
-      if (lane < 32) *reinterpret_cast<float4*>(dout + lane * 4) = v;
-      // (streaming stores for the mirror were measured: 0.341 - 0.346 against 0.333 - 0.339 ms per single image, same call)
-      if (HOST_MIRROR && dp.hdesc && lane < 32) *reinterpret_cast<float4*>(dp.hdesc + (obase + oidx) * dim + lane * 4) = v;
+      finish_descriptor128<HOST_MIRROR>(dp, lane, v, dout, hout);
     }
+  }
+}
+
+// ================================= descriptor, pixel raster ===================================
+//
+// HESS_DESC_ORDER_PIXEL (include/hess_abi.h; restated by oracle/hess_oracle.c, compute_descriptor_pixel): one wavefront
+// per feature rasters the bounding box of the rotated 5 x 5-cell footprint ONCE, 64 pixels per step, one per lane.
+// In the keypoint frame (u, v) = R(-angle)(pixel - keypoint) / spt everything the reference recomputes per (pixel,
+// cell) pair is a per-pixel quantity -- the gather, the Gaussian weight exp(-(u^2 + v^2)/8), the bin coordinate theta
+// and its split, and the bilinear cell weights (the split of u + 1.5, v + 1.5 between the two nearest cell indices) --
+// so a pixel costs one evaluation instead of up to four (2.56 on average), and then adds its weight to <= 2 x 2 cells x
+// 2 bins.  descriptor_kernel above spends 5.6 k vector instructions per feature (80 live iterations of 57).
+// The scatter is deterministic without any ordering: the sums are 32-bit FIXED POINT with a per-feature power-of-two
+// scale, every product is rounded to an integer before it is added (uint32(fma(b, w, 0.5))), and integer addition is
+// associative -- so LDS integer atomics give the same bits for every schedule, and the oracle's plain loop over the
+// pixels gives them too.  (ds_add_u64: 5.6 LDS cycles per wave-instruction whatever the lanes, tools/micro/
+// lds_atomic_int.hip; LDS FLOAT atomics take 170 - 225 cycles, lds_atomic.hip.)  The two bins a pixel touches in a
+// cell are neighbours (floor(theta) and the next, modulo 8): they are one 64-bit word [bin b0 | bin b0 + 1] of the
+// cell's "even" pairs (0,1) (2,3) (4,5) (6,7) or of its "odd" pairs (1,2) (3,4) (5,6) (7,0), so ONE ds_add_u64 adds
+// both (the low half cannot carry into the high one: the scale keeps every sum below 2^32, see the oracle); a bin is
+// the sum of its even-pair and odd-pair halves.  Four atomics per pixel.
+// Lanes that hit the same word serialise (about 3.3 cycles per extra lane), and neighbouring pixels do (coherent
+// gradients): a wavefront keeps PX_COPIES copies of the 128 words and a lane adds into copy (lane mod PX_COPIES); the
+// copies are summed when the raster is done.
+// Layout per wavefront: [copy][cell 0..15][even pairs 0..3, odd pairs 0..3] 64-bit words, copies PX_COPY_U64 words
+// apart (1 KB + 32 bytes: the copies of one word fall on different banks).
+constexpr int PX_COPIES = 8;
+constexpr int PX_COPY_U64 = 128 + 4;
+constexpr int PX_WAVE_U64 = PX_COPIES * PX_COPY_U64;
+
+// N consecutive steps of a lane: keypoint-frame coordinates (u = 3 marks a step outside the window or past the box),
+// gathered (gradient, theta)
+template <int N_>
+struct PixChunk {
+  static constexpr int N = N_;
+  float u[N_], v[N_];
+  float2 cc[N_];
+};
+
+template <bool HOST_MIRROR>
+__global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
+                                                               int cap_list, const FRec* recs,
+                                                               const int* fsrc, const int* feat_total,
+                                                               const int* feat_first, const int* img_base,
+                                                               const float* got, HostKeypoint* keys, float* desc,
+                                                               int cap_feat) {
+  __shared__ __attribute__((aligned(16))) float dl[4][128];
+  __shared__ __attribute__((aligned(16))) unsigned long long hist[4][PX_WAVE_U64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y + dp.first_image;
+  const int ftotal = feat_total[b], ffirst = feat_first[b];
+  const long long obase = img_base[b];
+  const int nwaves = gridDim.x * 4;
+  const float rpi = (float)(4.0 / kPI);
+  const int dim = dp.half_sift ? 64 : 128;
+
+  static_assert(sizeof(HostKeypoint) == 24 && sizeof(hist) >= 256 * 24, "record staging fits the sums");
+  keypoint_records<HOST_MIRROR>(dp, reinterpret_cast<uint32_t*>(&hist[0][0]), list, cap_list, recs, fsrc, cap_feat, b, ftotal, ffirst, obase, keys);
+  if (!desc) return;
+  unsigned long long* const sums = &hist[wv][0];
+  {
+    uint4* const z = reinterpret_cast<uint4*>(sums);
+    for (int i = lane; i < PX_WAVE_U64 / 2; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  unsigned long long* const mycopy = sums + (lane & (PX_COPIES - 1)) * PX_COPY_U64;
+  const uint32_t theta_end_bits = dp.dynamic_indexing ? 0x41000001u : 0x41000000u;  // 8.0f, or the next float (admits theta == 8)
+
+  // feature order: as descriptor_kernel (largest footprints first, blocks of consecutive features per XCD)
+  int mw0 = blockIdx.x * 4 + wv;
+  if (dp.xcd_block) {
+    const int xcd = blockIdx.x & 7, wx = (int)(blockIdx.x >> 3) * 4 + wv;
+    mw0 = ((wx / dp.xcd_block) * 8 + xcd) * dp.xcd_block + wx % dp.xcd_block;
+  }
+  for (int mw = mw0; mw < ftotal; mw += nwaves) {
+    const int m = ffirst + ftotal - 1 - mw;
+    const int src = fsrc[(long long)b * cap_feat + m];
+    const int i = src >> 2, k = src & 3;
+    const int oidx = m - ffirst;
+    const FRec rec = recs[(long long)b * cap_list + i];
+    const int li = list[(long long)b * cap_list + i].level_index;
+    int o, l;
+    level_of(g, li, &o, &l);
+    const OctGeom& og = g.o[o];
+    const unsigned long long gpa = (unsigned long long)(reinterpret_cast<const float2*>(got) + og.got_off +
+                                                        ((long long)(l - 1) * g.B + b) * og.plane);
+    const GlobalBytes gp = (GlobalBytes)(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gpa >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(gpa & 0xFFFFFFFFull)));
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)gp, 0, __builtin_amdgcn_readfirstlane(og.plane * 8), 0x00020000 /* raw 32-bit data, gfx9 family */);
+    const int width = og.wa, height = og.h;
+
+    const float kw = dp.multi ? (float)((2.0 * kPI / 255.0) * (double)((rec.w >> (8 * k)) & 0xFFu))
+                              : __uint_as_float(rec.w);
+    const float kx = (float)(rec.x & 0x00FFFFFFu) / 1024.0f;
+    const float ky = (float)(rec.y & 0x00FFFFFFu) / 1024.0f;
+    const float kz = (float)(rec.z & 0x0000FFFFu) / 256.0f;
+    const float spt = fabsf(kz * dp.window_factor);
+    float s, c;
+    dm_sincosf(kw, &s, &c);
+    const float anglef = (kw > kPI) ? (float)(kw - (2.0 * kPI)) : kw;
+    const float cspt = c * spt, sspt = s * spt;
+    const float crspt = c / spt, srspt = s / spt;
+    const float bsz = fabsf(cspt) + fabsf(sspt);
+    const float ext = 2.5f * bsz;  // half extent of the footprint's bounding box
+    const float xmin = fmaxf(1.5f, floorf(kx - ext) + 0.5f);
+    const float ymin = fmaxf(1.5f, floorf(ky - ext) + 0.5f);
+    const float xmax = fminf(width - 1.5f, floorf(kx + ext) + 0.5f);
+    const float ymax = fminf(height - 1.5f, floorf(ky + ext) + 0.5f);
+    // fixed-point scale 2^sh: 0.75 (spt + 1)^2 < 2^e bounds every sum, sh = 32 - e (the oracle's frexpf)
+    const float bound = 0.75f * (spt + 1.0f) * (spt + 1.0f);
+    const int sh = min(max(32 - ((int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126), 0), 30);
+    const float scale = __uint_as_float((uint32_t)(127 + sh) << 23), rscale = __uint_as_float((uint32_t)(127 - sh) << 23);
+    // (the same in every lane: the box is the feature's)
+    const int nxs = __builtin_amdgcn_readfirstlane((xmax >= xmin) ? (int)(xmax - xmin) + 1 : 0);
+    const int nys = __builtin_amdgcn_readfirstlane((ymax >= ymin) ? (int)(ymax - ymin) + 1 : 0);
+    const int total = nxs * nys;
+    const int nit = (total + 63) >> 6;
+    // Lane's pixel of step `it`: t = 64 it + lane -> (t % nxs, t / nxs).  Start by one exact division, then 64 places
+    // along the raster per step by exact float increments: 64 = a nxs + r, so x += r (and back by a row's length
+    // when that passes xmax), y += a (+ 1) -- integers + 0.5 far below 2^23.
+    const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
+    const int a64 = (int)((64.0f + 0.5f) * inv), r64 = 64 - a64 * nxs;  // (exact: |error| << 0.5/nxs)
+    const int sy0 = (int)(((float)lane + 0.5f) * inv), sx0 = lane - __mul24(sy0, nxs);
+    float xf = xmin + (float)sx0;
+    float yf = (total > 0) ? ymin + (float)sy0 : 3.0e38f;
+    unsigned goff = (unsigned)(((int)ymin + sy0) * width + (int)xmin + sx0) * 8u;
+    const float fr64 = (float)r64, fa64 = (float)a64, fnxs = (float)nxs;
+    const unsigned gstep = (unsigned)(a64 * width + r64) * 8u, gwrap = (unsigned)(width - nxs) * 8u;
+
+    // stage A: keypoint-frame coordinates, window test and gather of N steps, issued back to back
+    auto stage_a = [&](auto& ck) {
+      constexpr int N = std::remove_reference_t<decltype(ck)>::N;
+#pragma unroll
+      for (int q = 0; q < N; q++) {
+        const float dx = xf - kx, dy = yf - ky;
+        const float u = fmaf(crspt, dx, srspt * dy);
+        ck.v[q] = fmaf(crspt, dy, -(srspt * dx));
+        const bool in = (yf <= ymax) & (fabsf(u) < 2.5f) & (fabsf(ck.v[q]) < 2.5f);
+        ck.u[q] = in ? u : 3.0f;  // (outside the window: steps past the end of the box fail yf <= ymax)
+        const dfloat2 gv = __builtin_amdgcn_raw_buffer_load_b64(grsrc, (int)(in ? goff : 0u), 0, 0);
+        ck.cc[q] = make_float2(gv.x, gv.y);
+        xf += fr64;
+        const bool wrap = xf > xmax;
+        xf -= wrap ? fnxs : 0.0f;
+        yf += wrap ? fa64 + 1.0f : fa64;
+        goff += wrap ? gstep + gwrap : gstep;
+      }
+    };
+    // stage B: the pixel's weight, bin and cell split; four 64-bit additions of two fixed-point values each
+    auto stage_b = [&](const auto& ck) {
+      constexpr int N = std::remove_reference_t<decltype(ck)>::N;
+#pragma unroll
+      for (int q = 0; q < N; q++) {
+        const float u = ck.u[q], v = ck.v[q];
+        if (!__any(u < 2.5f)) continue;  // (wave-uniform) a step wholly outside the window: the box's corners
+        const float ww = dm_expf_inrange(-0.125f * fmaf(u, u, v * v));
+        float theta = (anglef - ck.cc[q].y) * rpi;
+        theta = (theta < 0) ? theta + 8.0f : theta;
+        // 0 <= theta < theta_end as ONE unsigned compare of the bit patterns (see descriptor_kernel)
+        const bool hit = (u < 2.5f) & (__float_as_uint(theta) < theta_end_bits);
+        const float fo = floorf(theta);
+        const float wb1 = theta - fo, wb0 = 1.0f - wb1;
+        const int b0 = (int)fo;  // 0..7 (8 with -di: the pair (0, 1) with weights (1, 0))
+        const int slot = ((b0 >> 1) & 3) + ((b0 & 1) << 2);  // even pair b0/2, or odd pair (b0-1)/2 behind the even ones
+        const float au = u + 1.5f, av = v + 1.5f;
+        const float fu = floorf(au), fv = floorf(av);
+        const int ix0 = (int)fu, iy0 = (int)fv;
+        const float wx1 = au - fu, wx0 = 1.0f - wx1;
+        const float wy1 = av - fv, wy0 = 1.0f - wy1;
+        const float wt = (ww * ck.cc[q].x) * scale;
+        const float a0 = wt * wy0, a1 = wt * wy1;
+        const float b00 = a0 * wx0, b01 = a0 * wx1, b10 = a1 * wx0, b11 = a1 * wx1;
+        unsigned long long* const p = mycopy + ((iy0 * 4 + ix0) * 8 + slot);
+        const bool vx0 = ix0 >= 0, vx1 = ix0 <= 2, vy0 = iy0 >= 0, vy1 = iy0 <= 2;
+#define HESS_PX_ADD(P, B)                                                                                          \
+  (void)__hip_atomic_fetch_add((P), (unsigned long long)__float2uint_rz(fmaf((B), wb0, 0.5f)) |                    \
+                                       ((unsigned long long)__float2uint_rz(fmaf((B), wb1, 0.5f)) << 32),           \
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+        if (hit & vy0 & vx0) HESS_PX_ADD(p, b00);
+        if (hit & vy0 & vx1) HESS_PX_ADD(p + 8, b01);
+        if (hit & vy1 & vx0) HESS_PX_ADD(p + 32, b10);
+        if (hit & vy1 & vx1) HESS_PX_ADD(p + 40, b11);
+#undef HESS_PX_ADD
+      }
+    };
+    {
+      constexpr int UN = 2;
+      // software pipeline: the gathers of the next chunk are in flight while the current chunk is accumulated
+      PixChunk<UN> ca, cb;
+      stage_a(ca);
+      for (int it0 = 0; it0 < nit; it0 += 2 * UN) {
+        stage_a(cb);
+        stage_b(ca);
+        if (it0 + UN >= nit) break;
+        stage_a(ca);
+        stage_b(cb);
+      }
+    }
+    // The copies' sums: lane j reads words 2j, 2j+1 of every copy (one 16-byte read each) and adds the four 32-bit halves
+    // apart; copies 1.. are cleared for the next feature, copy 0 takes the totals.
+    __builtin_amdgcn_wave_barrier();
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int cpy = 0; cpy < PX_COPIES; cpy++) {
+      uint4* const w = reinterpret_cast<uint4*>(sums + cpy * PX_COPY_U64 + 2 * lane);
+      const uint4 x = *w;
+      t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+      if (cpy) *w = make_uint4(0u, 0u, 0u, 0u);
+    }
+    *reinterpret_cast<uint4*>(sums + 2 * lane) = t;
+    __builtin_amdgcn_wave_barrier();
+    // lane (cell, q) owns bins 2q, 2q+1: even pair q = [2q | 2q+1], odd pair q-1 = [2q-1 | 2q], odd pair q = [2q+1 | 2q+2]
+    {
+      const int cell = lane >> 2, q = lane & 3;
+      const uint32_t* const cw = reinterpret_cast<const uint32_t*>(sums + cell * 8);
+      const uint2 ev = *reinterpret_cast<const uint2*>(cw + 2 * q);
+      const uint32_t od_hi = cw[8 + 2 * ((q + 3) & 3) + 1], od_lo = cw[8 + 2 * q];
+      const float f0 = (float)(ev.x + od_hi) * rscale, f1 = (float)(ev.y + od_lo) * rscale;
+      *reinterpret_cast<float2*>(&dl[wv][2 * lane]) = make_float2(f0, f1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<uint4*>(sums + 2 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    float* dout = desc + (obase + oidx) * dim;
+    float* hout = (HOST_MIRROR && dp.hdesc) ? dp.hdesc + (obase + oidx) * dim : nullptr;
+    if (dp.half_sift) {  // des[k] += des[k+4], ProgramCU.cu:1782-1785: lane < 32 -> cell lane/2, k = 2 (lane & 1) + {0, 1}
+      float2 v = make_float2(0, 0);
+      if (lane < 32) {
+        const float* cellp = &dl[wv][(lane >> 1) * 8 + (lane & 1) * 2];
+        const float2 lo = *reinterpret_cast<const float2*>(cellp), hi = *reinterpret_cast<const float2*>(cellp + 4);
+        v = make_float2(lo.x + hi.x, lo.y + hi.y);
+      }
+      finish_descriptor64<HOST_MIRROR>(dp, lane, v, dout, hout);
+    } else {
+      float4 v = make_float4(0, 0, 0, 0);
+      if (lane < 32) v = *reinterpret_cast<const float4*>(&dl[wv][lane * 4]);
+      finish_descriptor128<HOST_MIRROR>(dp, lane, v, dout, hout);
+    }
+    __builtin_amdgcn_wave_barrier();  // (dl and the sums are rewritten by the next feature)
   }
 }
 
@@ -845,7 +1102,10 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   hipLaunchKernelGGL((descriptor_kernel<MIRROR, SEQ>), dim3(blocks, batch), dim3(256), lds_pad, st, g, dpx, list, cap_list, \
                      recs, fsrc, feat_total, feat_first, img_base, got, keys, desc, cap_feat)
   const bool mirror = dp.hkeys || dp.hdesc;
-  if (dp.sequential) { if (mirror) HESS_DESC_LAUNCH(true, true); else HESS_DESC_LAUNCH(false, true); }
+  if (dp.pixel) {
+    if (mirror) hipLaunchKernelGGL((descriptor_pixel_kernel<true>), dim3(blocks, batch), dim3(256), 0, st, g, dpx, list, cap_list, recs, fsrc, feat_total, feat_first, img_base, got, keys, desc, cap_feat);
+    else hipLaunchKernelGGL((descriptor_pixel_kernel<false>), dim3(blocks, batch), dim3(256), 0, st, g, dpx, list, cap_list, recs, fsrc, feat_total, feat_first, img_base, got, keys, desc, cap_feat);
+  } else if (dp.sequential) { if (mirror) HESS_DESC_LAUNCH(true, true); else HESS_DESC_LAUNCH(false, true); }
   else { if (mirror) HESS_DESC_LAUNCH(true, false); else HESS_DESC_LAUNCH(false, false); }
 #undef HESS_DESC_LAUNCH
 }

@@ -58,7 +58,7 @@ enum { HESS_TRUNC_HIGHEST_0 = 0, HESS_TRUNC_HIGHEST_1 = 1, HESS_TRUNC_LOWEST = 2
  *                          on unit-norm descriptors, measured; the tests bound it by 1e-6; north star: 1e-4);
  *                          descriptor kernel 16 % faster, whole path + 7 %
  *   SEQUENTIAL             the reference's own order, sample after sample: bit-identical to a sequential scan */
-enum { HESS_DESC_ORDER_INTERLEAVED = 0, HESS_DESC_ORDER_SEQUENTIAL = 1 };
+enum { HESS_DESC_ORDER_INTERLEAVED = 0, HESS_DESC_ORDER_SEQUENTIAL = 1, HESS_DESC_ORDER_PIXEL = 2 };
 
 /* Pixel formats accepted by hess_run_* (the GL enums of SiftGPU::RunSIFT(w,h,data,fmt,type)
  * are mapped onto these by the C++ class; reference GLTexImage.cpp:918-1036). */

@@ -728,8 +728,108 @@ static void compute_orientation_existing(const hess_cpu_ctx* c, frec* rec, const
 /* ComputeDescriptor_Kernel<-di,HALF>, ProgramCU.cu:1650-1804 + NormalizeDescriptor_Kernel
  * :1950-2054.  `angle` is the un-mirrored float orientation handed to the kernel (key.w).    */
 
-static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float angle, const float* got,
+static void normalize_descriptor(const hess_cpu_ctx* c, float* d);
+
+/* HESS_DESC_ORDER_PIXEL (include/hess_abi.h; this build's order, NOT the reference's): every pixel of the keypoint's
+ * footprint is visited ONCE.  In the keypoint frame -- (u, v) = R(-angle) (pixel - keypoint) / spt, the 4 x 4 cell
+ * centres at -1.5 .. 1.5 -- the quantities the reference recomputes per (pixel, cell) pair from the cell's own rounded
+ * centre are per-pixel: nx + ix - 1.5 = u, so the Gaussian weight exp(-(u^2 + v^2) / 8) (ProgramCU.cu:1745-1748), the
+ * bin coordinate theta (:1750-1753) and the bilinear cell weights 1 - |nx|, 1 - |ny| = the split of u + 1.5, v + 1.5
+ * between the two nearest cell indices.  A pixel then adds weight * wy_j * wx_i * wbin_k to (at most) 2 x 2 cells x 2
+ * bins.  The sums are kept in 32-bit FIXED POINT with a per-keypoint power-of-two scale 2^sh (integer addition is
+ * associative: the result does not depend on the order of the pixels, so any parallel schedule gives these bits); each
+ * of the eight products is rounded to an integer by (uint32)(fma(b, w, 0.5)).  2^sh: a bin cannot exceed 0.7072 (the
+ * largest gradient/2 of luminance in [0, 1]) x the lattice sum of the cell's bilinear window (spt^2 to a fraction of
+ * a percent, < (spt + 1)^2: tools/r05/lattice_sum.py); with 0.75 (spt + 1)^2 < 2^e and sh = 32 - e the sums stay
+ * below 2^32.  The quantisation costs <= 2.2e-7 on unit-norm descriptors against sums in units of 2^-32 (measured).
+ * Against the reference's order (sequential float sums) the results differ by rounding -- of the per-pixel quantities
+ * (u instead of nx + offx) and of that order's own float arithmetic: for the worst feature of 640-2.jpg a float64
+ * evaluation of the reference's formula is 7.9e-6 from the sequential float order and 3.6e-7 from this one.  Tests
+ * bound the distance between the two by 1e-5 on unit-norm descriptors (north star 1e-4). */
+static inline uint32_t f2u_sat(float v) { /* v_cvt_u32_f32: truncation, saturating, NaN -> 0 */
+  if (!(v > 0.0f)) return 0u;
+  return v >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
+static void compute_descriptor_pixel(const hess_cpu_ctx* c, const frec* rec, float angle, const float* got,
+                                     int width, int height, float* d /* 128 or 64 */) {
+  const float rpi = (float)(4.0 / PI_D);
+  int half = c->p.half_sift;
+  float kx = FIXED_TO_FLOAT(rec->x & 0x00FFFFFFu, 10);
+  float ky = FIXED_TO_FLOAT(rec->y & 0x00FFFFFFu, 10);
+  float kz = FIXED_TO_FLOAT(rec->z & 0x0000FFFFu, 8);
+  float kw = angle;
+  float spt = fabsf(kz * c->p.desc_window_factor);
+  float s, co;
+  om_sincosf(kw, &s, &co);
+  float anglef = (kw > PI_D) ? (float)(kw - (2.0 * PI_D)) : kw;
+  float cspt = co * spt, sspt = s * spt;
+  float crspt = co / spt, srspt = s / spt;
+  float bsz = fabsf(cspt) + fabsf(sspt);
+  float ext = 2.5f * bsz; /* half extent of the rotated 5 x 5-cell square's bounding box */
+  float xmin = border_lo(c, kx - ext);
+  float ymin = border_lo(c, ky - ext);
+  float xmax = border_hi(c, kx + ext, width);
+  float ymax = border_hi(c, ky + ext, height);
+  int e;
+  (void)frexpf(0.75f * (spt + 1.0f) * (spt + 1.0f), &e);
+  int sh = 32 - e;
+  if (sh > 30) sh = 30;
+  if (sh < 0) sh = 0;
+  const float scale = ldexpf(1.0f, sh), rscale = ldexpf(1.0f, -sh);
+  uint32_t bins[16][8];
+  memset(bins, 0, sizeof(bins));
+  for (float y = ymin; y <= ymax; y += 1.0f) {
+    for (float x = xmin; x <= xmax; x += 1.0f) {
+      float dx = x - kx;
+      float dy = y - ky;
+      float u = fmaf(crspt, dx, srspt * dy);
+      float v = fmaf(crspt, dy, -(srspt * dx));
+      if (!((fabsf(u) < 2.5f) && (fabsf(v) < 2.5f))) continue;
+      const float* cc = got + 2 * ((long)(int)y * width + (int)x);
+      float ww = om_expf(-0.125f * fmaf(u, u, v * v));
+      float theta = (anglef - cc[1]) * rpi;
+      if (theta < 0) theta += 8.0f;
+      /* DYNAMIC_INDEXING = false drops a sample whose floor(theta) is 8 (:1763-1771); -di adds it to des[8] = des[0] */
+      if (!(theta >= 0.0f && (theta < 8.0f || (theta == 8.0f && c->p.dynamic_indexing)))) continue;
+      float fo = floorf(theta);
+      int b0 = (int)fo & 7, b1 = (b0 + 1) & 7;
+      float wb1 = theta - fo, wb0 = 1.0f - wb1;
+      float au = u + 1.5f, av = v + 1.5f;
+      float fu = floorf(au), fv = floorf(av);
+      int ix0 = (int)fu, iy0 = (int)fv;
+      float wx1 = au - fu, wx0 = 1.0f - wx1;
+      float wy1 = av - fv, wy0 = 1.0f - wy1;
+      float wt = (ww * cc[0]) * scale;
+      for (int j = 0; j < 2; j++) {
+        int iy = iy0 + j;
+        if (iy < 0 || iy > 3) continue;
+        float a = wt * (j ? wy1 : wy0);
+        for (int i = 0; i < 2; i++) {
+          int ix = ix0 + i;
+          if (ix < 0 || ix > 3) continue;
+          float b = a * (i ? wx1 : wx0);
+          bins[iy * 4 + ix][b0] += f2u_sat(fmaf(b, wb0, 0.5f));
+          bins[iy * 4 + ix][b1] += f2u_sat(fmaf(b, wb1, 0.5f));
+        }
+      }
+    }
+  }
+  for (int bidx = 0; bidx < 16; bidx++) {
+    float des[8];
+    for (int k = 0; k < 8; k++) des[k] = (float)bins[bidx][k] * rscale;
+    if (half) {
+      for (int k = 0; k < 4; k++) d[bidx * 4 + k] = des[k] + des[k + 4]; /* des[k] += des[k+4], ProgramCU.cu:1782-1785 */
+    } else {
+      for (int k = 0; k < 8; k++) d[bidx * 8 + k] = des[k];
+    }
+  }
+  normalize_descriptor(c, d);
+}
+
+static void compute_descriptor(const hess_cpu_ctx* c, int order, const frec* rec, float angle, const float* got,
                                int width, int height, float* d /* 128 or 64 */) {
+  if (order == HESS_DESC_ORDER_PIXEL) { compute_descriptor_pixel(c, rec, angle, got, width, height, d); return; }
   const float rpi = (float)(4.0 / PI_D);
   int half = c->p.half_sift;
   float kx = FIXED_TO_FLOAT(rec->x & 0x00FFFFFFu, 10);
@@ -759,7 +859,7 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
      * four sums added as (p0 + p1) + (p2 + p3) -- the product's default summation order, restated here so that the
      * comparison with the HIP path stays bitwise in that mode too.  tests/test_descriptor_order.py bounds the
      * difference between the two orders. */
-    const int interleaved = c->p.descriptor_order == HESS_DESC_ORDER_INTERLEAVED;
+    const int interleaved = order == HESS_DESC_ORDER_INTERLEAVED;
     float part[4][9];
     for (int q = 0; q < 4; ++q) for (int i = 0; i < 9; ++i) part[q][i] = 0.0f;
     unsigned t = 0; /* position in the scan of the box, outside-the-window samples included */
@@ -806,9 +906,14 @@ static void compute_descriptor(const hess_cpu_ctx* c, const frec* rec, float ang
       for (int k = 0; k < 8; k++) d[bidx * 8 + k] = des[k];
     }
   }
+  normalize_descriptor(c, d);
+}
+
+static void normalize_descriptor(const hess_cpu_ctx* c, float* d) {
   if (!c->p.normalize) return;
   /* NormalizeDescriptor_Kernel: 32 lanes, lane j owns 4 (2 in half mode) consecutive floats;
    * tree reduction of ND_WarpReduction (ProgramCU.cu:1954-1969); rsqrt modelled as 1/sqrtf. */
+  const int half = c->p.half_sift;
   int per = half ? 2 : 4;
   float part[32];
   for (int pass = 0; pass < 2; pass++) {
@@ -1048,7 +1153,10 @@ static int user_keypoint_path(hess_cpu_ctx* c, image_result* R) {
 #pragma omp parallel for schedule(dynamic, 8)
     for (int i = 0; i < n; i++) {
       int o = rlevel[i] / dog, l = rlevel[i] % dog + 1;
-      compute_descriptor(c, &recs[i], om_u2f(recs[i].w), py->got[o][l], c->g[o].wa, c->g[o].h, tmp + (size_t)i * dim);
+      /* (a keypoint list is described in a floating-point order: the pixel order's fixed-point scale assumes the
+       * contrast of a detected keypoint) */
+      compute_descriptor(c, p->descriptor_order == HESS_DESC_ORDER_PIXEL ? HESS_DESC_ORDER_INTERLEAVED : p->descriptor_order,
+                         &recs[i], om_u2f(recs[i].w), py->got[o][l], c->g[o].wa, c->g[o].h, tmp + (size_t)i * dim);
     }
     for (int i = 0; i < listed; i++) memcpy(R->desc + (size_t)kindex[i] * dim, tmp + (size_t)i * dim, (size_t)dim * 4);
     free(tmp);
@@ -1333,6 +1441,10 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   /* --- GetFeatureDescriptors, PyramidCU.cpp:491-553 --- */
   int dim = p->compute_descriptors ? (p->half_sift ? 64 : 128) : 0;
   c->desc_dim = dim;
+  /* the pixel order's fixed-point bound assumes luminance in [0, 1] (8- and 16-bit inputs): float pixels are taken as
+   * they are and keep the interleaved order (hess_pipeline.hip: the same rule) */
+  const int desc_order = (p->descriptor_order == HESS_DESC_ORDER_PIXEL && pixtype == HESS_PIX_F32) ? HESS_DESC_ORDER_INTERLEAVED
+                                                                                                   : p->descriptor_order;
   float* desc = NULL;
   if (dim) {
     desc = (float*)malloc((size_t)(total ? total : 1) * dim * sizeof(float));
@@ -1341,7 +1453,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
     for (int m = 0; m < total; m++) {
       int k = first + m;
       int o = flevel[k] / dog, l = flevel[k] % dog + 1;
-      compute_descriptor(c, &frecs[k], angles[k], py->got[o][l], c->g[o].wa, c->g[o].h, desc + (size_t)m * dim);
+      compute_descriptor(c, desc_order, &frecs[k], angles[k], py->got[o][l], c->g[o].wa, c->g[o].h, desc + (size_t)m * dim);
     }
   }
   t1 = now_ms(); c->timing[HESS_T_DESCRIPTOR] += (float)(t1 - t0); t0 = t1;

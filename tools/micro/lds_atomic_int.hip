@@ -10,13 +10,14 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 // MODE 0: ds_add_u32; 1: ds_add_u64; 2: private RMW (read, fma, write); 3: ds_add_rtn_u32 (value used)
+// MODE 4 / 5: ds_add_u32 / ds_add_u64 with only some lanes active (SAME = pattern: 1 = odd lanes, 2 = a scattered half, 3 = lanes 0..31, 4 = a scattered quarter)
 template <int MODE, int SAME>
 __global__ __launch_bounds__(256) void lds_kernel(unsigned* out, int iters) {
   __shared__ unsigned long long h[4][8][64 + 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int i = lane; i < 8 * 72; i += 64) (&h[wv][0][0])[i] = 0ull;
   __syncthreads();
-  const int slot = (MODE == 2) ? lane : lane / SAME;
+  const int slot = (MODE == 2 || MODE >= 4) ? lane : lane / SAME;
   unsigned v = 1u + lane;
   unsigned acc = 0;
   for (int i = 0; i < iters; i++) {
@@ -30,9 +31,16 @@ __global__ __launch_bounds__(256) void lds_kernel(unsigned* out, int iters) {
       } else if (MODE == 2) {
         volatile float* p = reinterpret_cast<volatile float*>(&h[wv][k][0]) + slot;
         *p = fmaf((float)v, 0.5f, *p);
-      } else {
+      } else if (MODE == 3) {
         unsigned* p = reinterpret_cast<unsigned*>(&h[wv][k][0]) + slot;
         acc += __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        const unsigned hsh = ((unsigned)lane * 2654435761u) >> 13;
+        const bool on = SAME == 1 ? (lane & 1) : SAME == 2 ? (hsh & 1) : SAME == 3 ? (lane < 32) : ((hsh & 3) == 0);
+        if (on) {
+          if (MODE == 4) (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&h[wv][k][0]) + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else (void)__hip_atomic_fetch_add(&h[wv][k][lane], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     v += 3u;
@@ -78,6 +86,14 @@ int main() {
     run(lds_kernel<1, 16>, w, "ds_add_u64, 16 lanes per address");
     run(lds_kernel<3, 1>, w, "ds_add_rtn_u32, 64 addresses");
     run(lds_kernel<3, 8>, w, "ds_add_rtn_u32, 8 lanes per address");
+    run(lds_kernel<4, 1>, w, "ds_add_u32, odd lanes only");
+    run(lds_kernel<4, 2>, w, "ds_add_u32, a scattered half");
+    run(lds_kernel<4, 3>, w, "ds_add_u32, lanes 0..31");
+    run(lds_kernel<4, 4>, w, "ds_add_u32, a scattered quarter");
+    run(lds_kernel<5, 1>, w, "ds_add_u64, odd lanes only");
+    run(lds_kernel<5, 2>, w, "ds_add_u64, a scattered half");
+    run(lds_kernel<5, 3>, w, "ds_add_u64, lanes 0..31");
+    run(lds_kernel<5, 4>, w, "ds_add_u64, a scattered quarter");
   }
   return 0;
 }
