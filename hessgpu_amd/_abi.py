@@ -7,7 +7,7 @@ CPU oracle's `hess_cpu_` entry points with the same table so both sides read ali
 """
 import ctypes as C
 
-HESS_ABI_VERSION = 3
+HESS_ABI_VERSION = 4
 
 HESS_OK = 0
 HESS_ERR_ARG = -1

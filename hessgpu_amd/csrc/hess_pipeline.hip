@@ -398,6 +398,7 @@ void default_params(hess_params* p) {
   p->truncate_method = HESS_TRUNC_HIGHEST_0;
   p->feature_count_threshold = -1;
   p->tex_max_dim = 3200;
+  p->descriptor_order = HESS_DESC_ORDER_PIXEL;
 }
 
 // ProgramCU::CreateFilterKernel, ProgramCU.cu:423-453 (host arithmetic, libm expf).
@@ -959,7 +960,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.xcd_block = c->desc_xcd_block;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   // the pixel order's fixed point assumes luminance in [0, 1] (8- and 16-bit inputs); float pixels are taken as they are
-  // and keep the interleaved order (oracle/hess_oracle.c: the same rule)
+  // and keep the interleaved order (the test oracle applies the same rule)
   dsp.pixel = p.descriptor_order == HESS_DESC_ORDER_PIXEL && pixtype != HESS_PIX_F32;
   // Delivered by the copier thread, a batch of four or more images gets its descriptors in two launches (the images
   // are independent and packed back to back): the first half's results cross the host link while the second half is
@@ -1583,7 +1584,9 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (params) c->p = *params; else default_params(&c->p);
   bool reserved_nonzero = false;
   for (int r : c->p.reserved) reserved_nonzero = reserved_nonzero || r != 0;
-  if (c->p.abi_version == 2 && c->p.descriptor_order == 0) c->p.abi_version = HESS_ABI_VERSION;  // a version-2 struct: same layout, the new word zero
+  // version-2 / -3 structs: same layout; 0 in the order word is what they ask for (the interleaved order, their default)
+  if ((c->p.abi_version == 2 && c->p.descriptor_order == 0) || (c->p.abi_version == 3 && c->p.descriptor_order <= HESS_DESC_ORDER_SEQUENTIAL))
+    c->p.abi_version = HESS_ABI_VERSION;
   if (c->p.abi_version != HESS_ABI_VERSION || c->p.dog_level_num < 0 || c->p.dog_level_num > kMaxDog ||
       c->p.descriptor_order < 0 || c->p.descriptor_order > HESS_DESC_ORDER_PIXEL || reserved_nonzero) {        // reserved words must be zero (word 0 is the test oracle's detector switch: not a product option)
     fprintf(stderr, "hessgpu: bad hess_params (abi_version %d)\n", c->p.abi_version);

@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 
 // ================================= descriptor, pixel raster ===================================
 //
-// HESS_DESC_ORDER_PIXEL (include/hess_abi.h; restated by oracle/hess_oracle.c, compute_descriptor_pixel): one wavefront
+// HESS_DESC_ORDER_PIXEL (include/hess_abi.h; restated by the test oracle, compute_descriptor_pixel): one wavefront
 // per feature rasters the bounding box of the rotated 5 x 5-cell footprint ONCE, 64 pixels per step, one per lane.
 // In the keypoint frame (u, v) = R(-angle)(pixel - keypoint) / spt everything the reference recomputes per (pixel,
 // cell) pair is a per-pixel quantity -- the gather, the Gaussian weight exp(-(u^2 + v^2)/8), the bin coordinate theta
@@ -847,7 +847,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 // copies are summed when the raster is done.
 // Layout per wavefront: [copy][cell 0..15][even pairs 0..3, odd pairs 0..3] 64-bit words, copies PX_COPY_U64 words
 // apart (1 KB + 32 bytes: the copies of one word fall on different banks).
-constexpr int PX_COPIES = 8;
+#ifndef HESS_PX_COPIES
+#define HESS_PX_COPIES 8
+#endif
+#ifndef HESS_PX_UNROLL
+#define HESS_PX_UNROLL 2
+#endif
+constexpr int PX_COPIES = HESS_PX_COPIES;  // (A/B builds: -DHESS_PX_COPIES=4|16, -DHESS_PX_UNROLL=1|3)
 constexpr int PX_COPY_U64 = 128 + 4;
 constexpr int PX_WAVE_U64 = PX_COPIES * PX_COPY_U64;
 
@@ -1008,7 +1014,7 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
       }
     };
     {
-      constexpr int UN = 2;
+      constexpr int UN = HESS_PX_UNROLL;
       // software pipeline: the gathers of the next chunk are in flight while the current chunk is accumulated
       PixChunk<UN> ca, cb;
       stage_a(ca);

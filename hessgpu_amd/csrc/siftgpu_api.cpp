@@ -321,6 +321,8 @@ void SiftGPU::PrintUsage() {
                "-topk <n> -tc/-tc1/-tc2/-tc3 <n>         limit the number of features\n"
                "-half -sd -b -bvlf -ads -maxd <n> -p WxH -tight -cuda <dev> -v <0..4>\n"
                "-dseq                                    descriptor bins summed in the reference's sequential order\n"
+               "-dint                                    ... as four interleaved partial sums (default: one pass over the pixels,\n"
+               "                                         fixed-point sums; include/hess_abi.h, HESS_DESC_ORDER_*)\n"
                "                                         (default: four interleaved partial sums, 16 % faster, equal within 1e-6)\n"
                "Image files: PGM / PPM (P2 P3 P5 P6), and PNG when libpng16.so.16 is present at run time -- this build has no\n"
                "DevIL; decode JPEG in the caller and hand the pixels to RunSIFT(width, height, data, gl_format, gl_type).\n";
@@ -369,6 +371,7 @@ void SiftGPU::ParseParam(int argc, char** argv) {  // SiftGPU.cpp:855-1380
       continue;  // accepted, no effect on this backend
     if (k == "di") { p.dynamic_indexing = 1; continue; }  // SiftGPU.cpp:1030-1032
     if (k == "dseq") { p.descriptor_order = HESS_DESC_ORDER_SEQUENTIAL; continue; }  // this build only: hess_abi.h
+    if (k == "dint") { p.descriptor_order = HESS_DESC_ORDER_INTERLEAVED; continue; }
     if (k == "sd") { if (!_initialized) p.compute_descriptors = 0; continue; }
     if (k == "b") { im->binary_sift = 1; continue; }
     if (k == "ads") { p.auto_downscale = 1; continue; }

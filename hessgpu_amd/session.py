@@ -193,7 +193,7 @@ class Session:
 
     def keep_levels(self, on=True):
         """Product: also store the top Gaussian level of every octave (never materialised by default) so that
-        level(..., DBG_GAUSS) can return it; the oracle keeps all levels anyway (hess_cpu_keep_levels)."""
+        level(..., DBG_GAUSS) can return it; the test oracle keeps all levels anyway."""
         if "debug_keep_levels" in self._f:
             self._check(self._f["debug_keep_levels"](self._h, int(on)))
 

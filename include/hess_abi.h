@@ -30,8 +30,11 @@ extern "C" {
  * 3: hess_share_results / hess_shared_results_info (added during version 2 without a bump: round 3);
  *    hess_params.descriptor_order (the first of the reserved words: a version-2 struct, all zero there, asks for
  *    the default); hess_count / hess_fetch / hess_device_results refuse (HESS_ERR_ARG / _STATE) after a failed run
- *    instead of handing out the results of the run before. */
-#define HESS_ABI_VERSION 3
+ *    instead of handing out the results of the run before.
+ * 4: HESS_DESC_ORDER_PIXEL, the order hess_default_params now chooses (a version-3 struct keeps what it asks for: 0 is
+ *    the interleaved order); hess_debug_keep_levels (the top Gaussian level of an octave is no longer written to HBM
+ *    unless asked for); a context whose DMA copy was lost refuses further runs (HESS_ERR_DEVICE, "poisoned"). */
+#define HESS_ABI_VERSION 4
 
 typedef enum hess_status {
   HESS_OK = 0,
@@ -52,12 +55,22 @@ enum { HESS_TRUNC_HIGHEST_0 = 0, HESS_TRUNC_HIGHEST_1 = 1, HESS_TRUNC_LOWEST = 2
 
 /* Order in which the samples of a descriptor cell are added into its orientation bins (ComputeDescriptor_Kernel,
  * ProgramCU.cu:1723-1774: one thread per cell walks the cell's box row by row and adds as it goes).
- *   INTERLEAVED (default)  four partial sums per bin -- the samples at positions 0, 1, 2, 3 modulo 4 of that walk --
+ *   SEQUENTIAL             the reference's own order, sample after sample: bit-identical to a sequential scan
+ *   INTERLEAVED            four partial sums per bin -- the samples at positions 0, 1, 2, 3 modulo 4 of that walk --
  *                          added as (p0 + p1) + (p2 + p3): every lane of the kernel keeps its own samples' sums, no
  *                          cross-lane exchange per sample; differs from the sequential sum by rounding only (<= 3e-7
  *                          on unit-norm descriptors, measured; the tests bound it by 1e-6; north star: 1e-4);
- *                          descriptor kernel 16 % faster, whole path + 7 %
- *   SEQUENTIAL             the reference's own order, sample after sample: bit-identical to a sequential scan */
+ *                          descriptor kernel 16 % faster than SEQUENTIAL
+ *   PIXEL (default)        every pixel of the footprint is evaluated ONCE (gather, Gaussian weight, bin split in the
+ *                          keypoint's frame: the reference re-evaluates it for each of the up to four cells it belongs
+ *                          to) and adds its weight to <= 2 x 2 cells x 2 bins in 32-bit fixed point with a per-keypoint
+ *                          power-of-two scale -- integer sums, so the result does not depend on the order of the
+ *                          additions (any parallel schedule gives the same bits; the oracle's plain loop does).  Within
+ *                          6e-6 of SEQUENTIAL on unit-norm descriptors (measured; most of it SEQUENTIAL's own float
+ *                          rounding: a float64 evaluation of the reference's formula is 20 x closer to PIXEL), bounded by
+ *                          1e-5 in the tests; north star 1e-4.  Descriptor kernel a further 21 % faster, whole path + 9 %.
+ *                          Needs luminance in [0, 1] for its overflow bound: float pixels (HESS_PIX_F32, taken as they
+ *                          are) and user keypoint lists are described in the INTERLEAVED order instead. */
 enum { HESS_DESC_ORDER_INTERLEAVED = 0, HESS_DESC_ORDER_SEQUENTIAL = 1, HESS_DESC_ORDER_PIXEL = 2 };
 
 /* Pixel formats accepted by hess_run_* (the GL enums of SiftGPU::RunSIFT(w,h,data,fmt,type)

@@ -106,6 +106,7 @@ void hess_cpu_default_params(hess_params* p) {
   p->subpixel = 1;
   p->max_orientation = 2;
   p->compute_descriptors = 1;
+  p->descriptor_order = HESS_DESC_ORDER_PIXEL;
   p->normalize = 1;
   p->truncate_method = HESS_TRUNC_HIGHEST_0;
   p->feature_count_threshold = -1;

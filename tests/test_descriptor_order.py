@@ -56,9 +56,8 @@ def test_gpu_sequential_order_is_bitwise_the_oracles(kw):
             ok, od = o.fetch(i)
             assert gk.tobytes() == ok.tobytes() and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (kw, i)
         g.close()
-    # the default order on the same images: equal keypoints, descriptors within the tolerance (and bitwise the oracle's
-    # default order: every other parity test)
-    g = hessgpu_amd.HessContext(0, **kw)
+    # the interleaved order on the same images: equal keypoints, descriptors within the tolerance
+    g = hessgpu_amd.HessContext(0, descriptor_order=0, **kw)
     g.run(imgs)
     for i in range(len(imgs)):
         gk, gd = g.fetch(i)
