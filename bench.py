@@ -418,7 +418,7 @@ def main():
         if bound is not None:
             out["config"]["cpu_binding"] = f"{len(bound)} CPUs local to the rank's GPU"
         if prof is not None:
-            roofs = rooflines(prof, roof_steps, timed_keys, B, prof_mirror, _mirror_is_default(B))
+            roofs = rooflines(prof, roof_steps, timed_keys, B, prof_mirror, _mirror_is_default(B), desc_order)
             ranked = sorted(roofs, key=lambda r: -r["ms_per_step"])
             if ranked:
                 out["roofline"] = ranked[0]
@@ -578,7 +578,7 @@ def configs4_leg(local_rank, torch):
         "Mpix_per_s_three_contexts": round(S * S / dt / 1e6, 1), "ms_per_image_three_contexts": round(dt * 1e3, 3),
         "kernel_ms_per_image": {k: round(v["ms"] / 5, 4) for k, v in prof.items() if v["launches"]},
         "roofline_descriptor": {
-            "bound": "hbm", "kernel": "descriptor_kernel<false, false> (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
+            "bound": "hbm", "kernel": _desc_kernel_name(int(ctxs[0].params.descriptor_order), _mirror_is_default(1)) + " (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / dur / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1), "features_per_launch": n,
         },
@@ -607,7 +607,14 @@ def _mirror_is_default(batch):
     return batch <= int(os.environ.get("HESS_MIRROR_MAX_BATCH", "2"))
 
 
-def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
+def _desc_kernel_name(order, mirror):
+    """The descriptor launch as a rocprofv3 trace prints it: descriptor_pixel_kernel<host mirror> for the pixel order,
+    descriptor_kernel<host mirror, sequential order> for the float orders."""
+    m = "true" if mirror else "false"
+    return f"descriptor_pixel_kernel<{m}>" if order == 2 else f"descriptor_kernel<{m}, {'true' if order == 1 else 'false'}>"
+
+
+def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False, order=2):
     """Roofline entries of the two heavy kernels from the single-stream profile leg (prof); prof_other: the same leg
     with the other form of the descriptor launch."""
     import numpy as np
@@ -666,10 +673,11 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
         nfeat = int(round(nfeat / per_step))
         dur = d["ms"] * 1e-3 / d["launches"]
         achieved = fbytes / dur / 1e9
-        # (kernel names as a rocprofv3 trace prints them: descriptor_kernel<host mirror, sequential order>)
-        names = {False: "descriptor_kernel<false, false> (one wavefront per feature: rotated-grid histogram + normalisation + packed "
+        what = ("one wavefront per feature: one raster over the footprint, fixed-point sums" if order == 2 else
+                "one wavefront per feature: rotated-grid histogram")
+        names = {False: _desc_kernel_name(order, False) + f" ({what} + normalisation + packed "
                         "result stores in HBM; the copier thread's DMA copy takes them to the host)",
-                 True: "descriptor_kernel<true, false> (one wavefront per feature: rotated-grid histogram + normalisation + result "
+                 True: _desc_kernel_name(order, True) + f" ({what} + normalisation + result "
                        "stores incl. the pinned host mirror)"}
         e = {
             "bound": "hbm",
@@ -691,9 +699,9 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False):
             e["without_host_mirror" if mirror else "with_host_mirror"] = {
                 "avg_launch_us": round(ddur * 1e6, 2), "achieved": round(dbytes / ddur / 1e9, 1), "unit": "GB/s",
                 "launches_per_step": max(1, round(dd["launches"] / steps)),
-                "kernel": "descriptor_kernel<false, false>" if mirror else "descriptor_kernel<true, false>",
+                "kernel": _desc_kernel_name(order, not mirror),
                 "note": "same launch on a context created with HESS_DELIVERY=" + ("dma" if mirror else "mirror") +
-                        ": descriptor_kernel<true, ..> also stores keypoints + descriptors into pinned host memory and, "
+                        ": the <true> form also stores keypoints + descriptors into pinned host memory and, "
                         "alone on the device, waits for PCIe",
             }
         out.append(e)
@@ -745,20 +753,25 @@ def _host_cores():
     return max(1, min(n, 16))
 
 
-PARITY_TOL_VS_REFERENCE_ORDER = 1e-5   # unit-norm descriptors; the north star allows 1e-4 (tests/test_gpu_parity.py: TOL_ORDER)
+PARITY_TOL_VS_REFERENCE_ORDER = 1e-5   # unit-norm descriptors, 1080p; the north star allows 1e-4 (tests/test_gpu_parity.py: TOL_ORDER)
+PARITY_TOL_VS_FORMULA = 1e-6           # against the reference's formula in double precision (oracle, HESS_ORACLE_DESC_EXACT = 3)
 _parity_detail = {}
 
 
 def parity_check(img0, gk, gd, order=0):
-    """Image 0 of the timed run against the CPU oracle on the same pixels: keypoints and descriptors bit for bit against
-    the oracle's restatement of the SAME descriptor summation order (hess_params.descriptor_order), and keypoints bit for
-    bit + descriptors within PARITY_TOL_VS_REFERENCE_ORDER against the REFERENCE's sequential order (ProgramCU.cu:1723-1774)."""
+    """Image 0 of the timed run against the CPU oracle on the same pixels:
+      same_order       keypoints and descriptors bit for bit against the oracle's restatement of the SAME descriptor
+                       summation order (hess_params.descriptor_order);
+      reference_order  keypoints bit for bit, descriptors within PARITY_TOL_VS_REFERENCE_ORDER of the REFERENCE's sequential
+                       float order (ProgramCU.cu:1723-1774);
+      formula          descriptors against the reference's formula evaluated in double precision (what every float order
+                       approximates; the sequential float order is itself ~6e-6 from it at 1080p)."""
     import numpy as np
     from hessgpu_amd import _abi
     from oracle_lib import OracleSession  # the checker
 
     res = {}
-    for name, o_order in (("same_order", order), ("reference_order", _abi.DESC_ORDER_SEQUENTIAL)):
+    for name, o_order in (("same_order", order), ("reference_order", _abi.DESC_ORDER_SEQUENTIAL), ("formula", 3)):
         o = OracleSession(threads=_host_cores(), keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
                           descriptor_order=o_order)
         o.run(img0[None])
@@ -767,14 +780,20 @@ def parity_check(img0, gk, gd, order=0):
         keys_equal = bool(len(ok) == len(gk) and ok.tobytes() == gk.tobytes())
         bitwise = bool(keys_equal and np.array_equal(od.view(np.uint32), gd.view(np.uint32)))
         diff = float(np.abs(od.astype(np.float64) - gd.astype(np.float64)).max()) if keys_equal and od.size else (0.0 if keys_equal else float("inf"))
-        res[name] = (keys_equal, bitwise, diff)
-    good = res["same_order"][1] and res["reference_order"][0] and res["reference_order"][2] <= PARITY_TOL_VS_REFERENCE_ORDER
+        res[name] = (keys_equal, bitwise, diff, od)
+    seq_vs_formula = float(np.abs(res["reference_order"][3].astype(np.float64) - res["formula"][3]).max()) if res["formula"][3].size else 0.0
+    tol_formula = PARITY_TOL_VS_FORMULA if order == _abi.DESC_ORDER_PIXEL else PARITY_TOL_VS_REFERENCE_ORDER
+    good = (res["same_order"][1] and res["reference_order"][0] and res["reference_order"][2] <= PARITY_TOL_VS_REFERENCE_ORDER
+            and res["formula"][2] <= tol_formula)
     _parity_detail.update({
         "descriptor_order": {0: "interleaved", 1: "sequential (the reference's)", 2: "pixel raster, fixed point"}.get(order, str(order)),
         "bitwise_vs_oracle_in_the_same_order": res["same_order"][1],
         "keypoints_bitwise_vs_oracle_in_the_reference_order": res["reference_order"][0],
         "descriptor_max_abs_diff_vs_reference_order": max(_parity_detail.get("descriptor_max_abs_diff_vs_reference_order", 0.0), res["reference_order"][2]),
         "tolerance_vs_reference_order": PARITY_TOL_VS_REFERENCE_ORDER,
+        "descriptor_max_abs_diff_vs_reference_formula_in_double": max(_parity_detail.get("descriptor_max_abs_diff_vs_reference_formula_in_double", 0.0), res["formula"][2]),
+        "tolerance_vs_reference_formula": tol_formula,
+        "reference_order_vs_its_own_formula_in_double": max(_parity_detail.get("reference_order_vs_its_own_formula_in_double", 0.0), seq_vs_formula),
     })
     return bool(good)
 

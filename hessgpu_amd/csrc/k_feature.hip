@@ -838,22 +838,22 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 // associative -- so LDS integer atomics give the same bits for every schedule, and the oracle's plain loop over the
 // pixels gives them too.  (ds_add_u64: 5.6 LDS cycles per wave-instruction whatever the lanes, tools/micro/
 // lds_atomic_int.hip; LDS FLOAT atomics take 170 - 225 cycles, lds_atomic.hip.)  The two bins a pixel touches in a
-// cell are neighbours (floor(theta) and the next, modulo 8): they are one 64-bit word [bin b0 | bin b0 + 1] of the
-// cell's "even" pairs (0,1) (2,3) (4,5) (6,7) or of its "odd" pairs (1,2) (3,4) (5,6) (7,0), so ONE ds_add_u64 adds
-// both (the low half cannot carry into the high one: the scale keeps every sum below 2^32, see the oracle); a bin is
-// the sum of its even-pair and odd-pair halves.  Four atomics per pixel.
+// cell are neighbours (b0 = floor(theta) and the next, modulo 8): a cell keeps eight 64-bit words, word b0 = [bin b0 |
+// bin b0 + 1 mod 8], so ONE ds_add_u64 adds both (the low half cannot carry into the high one: the scale keeps every
+// sum below 2^32, see the oracle); bin k is the low half of word k plus the high half of word k - 1.  Four atomics per
+// pixel.
 // Lanes that hit the same word serialise (about 3.3 cycles per extra lane), and neighbouring pixels do (coherent
 // gradients): a wavefront keeps PX_COPIES copies of the 128 words and a lane adds into copy (lane mod PX_COPIES); the
 // copies are summed when the raster is done.
-// Layout per wavefront: [copy][cell 0..15][even pairs 0..3, odd pairs 0..3] 64-bit words, copies PX_COPY_U64 words
-// apart (1 KB + 32 bytes: the copies of one word fall on different banks).
+// Layout per wavefront: [copy][cell 0..15][word 0..7] 64-bit words, copies PX_COPY_U64 words apart (1 KB + 32 bytes:
+// the copies of one word fall on different banks).
 #ifndef HESS_PX_COPIES
-#define HESS_PX_COPIES 8
+#define HESS_PX_COPIES 4
 #endif
 #ifndef HESS_PX_UNROLL
 #define HESS_PX_UNROLL 2
 #endif
-constexpr int PX_COPIES = HESS_PX_COPIES;  // (A/B builds: -DHESS_PX_COPIES=4|16, -DHESS_PX_UNROLL=1|3)
+constexpr int PX_COPIES = HESS_PX_COPIES;  // (A/B builds: -DHESS_PX_COPIES=2|8, -DHESS_PX_UNROLL=1|3; same call, descriptor ms per step of 8: 2 copies 0.230, 4: 0.226, 8: 0.269 -- with eight the LDS footprint holds the kernel at four wavefronts per SIMD -- 16: 0.50)
 constexpr int PX_COPY_U64 = 128 + 4;
 constexpr int PX_WAVE_U64 = PX_COPIES * PX_COPY_U64;
 
@@ -865,6 +865,8 @@ struct PixChunk {
   float u[N_], v[N_];
   float2 cc[N_];
 };
+
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
 template <bool HOST_MIRROR>
 __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
@@ -891,7 +893,8 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
     uint4* const z = reinterpret_cast<uint4*>(sums);
     for (int i = lane; i < PX_WAVE_U64 / 2; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
-  unsigned long long* const mycopy = sums + (lane & (PX_COPIES - 1)) * PX_COPY_U64;
+  // LDS byte address of the lane's copy, as a float (stage B adds the word's offset in floating point)
+  const float mycopy_f = (float)(unsigned)(unsigned long long)(lds_u64*)(sums + (lane & (PX_COPIES - 1)) * PX_COPY_U64);
   const uint32_t theta_end_bits = dp.dynamic_indexing ? 0x41000001u : 0x41000000u;  // 8.0f, or the next float (admits theta == 8)
 
   // feature order: as descriptor_kernel (largest footprints first, blocks of consecutive features per XCD)
@@ -976,7 +979,9 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
         goff += wrap ? gstep + gwrap : gstep;
       }
     };
-    // stage B: the pixel's weight, bin and cell split; four 64-bit additions of two fixed-point values each
+    // stage B: the pixel's weight, bin and cell split; four 64-bit additions of two fixed-point values each.
+    // (The word's LDS address is formed in floating point from the three floors -- small integers, exact -- and
+    // converted once; the four cells' validity masks are combined as wave masks on the scalar unit.)
     auto stage_b = [&](const auto& ck) {
       constexpr int N = std::remove_reference_t<decltype(ck)>::N;
 #pragma unroll
@@ -987,29 +992,30 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
         float theta = (anglef - ck.cc[q].y) * rpi;
         theta = (theta < 0) ? theta + 8.0f : theta;
         // 0 <= theta < theta_end as ONE unsigned compare of the bit patterns (see descriptor_kernel)
-        const bool hit = (u < 2.5f) & (__float_as_uint(theta) < theta_end_bits);
-        const float fo = floorf(theta);
+        const uint64_t m_hit = __builtin_amdgcn_ballot_w64((u < 2.5f) & (__float_as_uint(theta) < theta_end_bits));
+        // b0 = floor(theta), 0..7; theta == 8 (-di only) counts as b0 = 7 with weights (0, 1): the same sums, since word
+        // 7 = [bin 7 | bin 0] (the oracle says bin 0 += weight, bin 1 += 0)
+        const float fo = fminf(floorf(theta), 7.0f);
         const float wb1 = theta - fo, wb0 = 1.0f - wb1;
-        const int b0 = (int)fo;  // 0..7 (8 with -di: the pair (0, 1) with weights (1, 0))
-        const int slot = ((b0 >> 1) & 3) + ((b0 & 1) << 2);  // even pair b0/2, or odd pair (b0-1)/2 behind the even ones
         const float au = u + 1.5f, av = v + 1.5f;
-        const float fu = floorf(au), fv = floorf(av);
-        const int ix0 = (int)fu, iy0 = (int)fv;
+        const float fu = floorf(au), fv = floorf(av);  // -1 .. 3: cells fu, fu + 1 / fv, fv + 1 where they exist
         const float wx1 = au - fu, wx0 = 1.0f - wx1;
         const float wy1 = av - fv, wy0 = 1.0f - wy1;
         const float wt = (ww * ck.cc[q].x) * scale;
         const float a0 = wt * wy0, a1 = wt * wy1;
         const float b00 = a0 * wx0, b01 = a0 * wx1, b10 = a1 * wx0, b11 = a1 * wx1;
-        unsigned long long* const p = mycopy + ((iy0 * 4 + ix0) * 8 + slot);
-        const bool vx0 = ix0 >= 0, vx1 = ix0 <= 2, vy0 = iy0 >= 0, vy1 = iy0 <= 2;
+        const unsigned addr = (unsigned)(int)fmaf(fv, 256.0f, fmaf(fu, 64.0f, fmaf(fo, 8.0f, mycopy_f)));  // byte address in LDS
+        lds_u64* const p = (lds_u64*)(unsigned long long)addr;
+        const uint64_t mx0 = __builtin_amdgcn_ballot_w64(fu >= 0.0f), mx1 = __builtin_amdgcn_ballot_w64(fu <= 2.0f);
+        const uint64_t my0 = m_hit & __builtin_amdgcn_ballot_w64(fv >= 0.0f), my1 = m_hit & __builtin_amdgcn_ballot_w64(fv <= 2.0f);
 #define HESS_PX_ADD(P, B)                                                                                          \
   (void)__hip_atomic_fetch_add((P), (unsigned long long)__float2uint_rz(fmaf((B), wb0, 0.5f)) |                    \
                                        ((unsigned long long)__float2uint_rz(fmaf((B), wb1, 0.5f)) << 32),           \
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-        if (hit & vy0 & vx0) HESS_PX_ADD(p, b00);
-        if (hit & vy0 & vx1) HESS_PX_ADD(p + 8, b01);
-        if (hit & vy1 & vx0) HESS_PX_ADD(p + 32, b10);
-        if (hit & vy1 & vx1) HESS_PX_ADD(p + 40, b11);
+        if (__builtin_amdgcn_inverse_ballot_w64(my0 & mx0)) HESS_PX_ADD(p, b00);
+        if (__builtin_amdgcn_inverse_ballot_w64(my0 & mx1)) HESS_PX_ADD(p + 8, b01);
+        if (__builtin_amdgcn_inverse_ballot_w64(my1 & mx0)) HESS_PX_ADD(p + 32, b10);
+        if (__builtin_amdgcn_inverse_ballot_w64(my1 & mx1)) HESS_PX_ADD(p + 40, b11);
 #undef HESS_PX_ADD
       }
     };
@@ -1026,8 +1032,10 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
         stage_b(cb);
       }
     }
-    // The copies' sums: lane j reads words 2j, 2j+1 of every copy (one 16-byte read each) and adds the four 32-bit halves
-    // apart; copies 1.. are cleared for the next feature, copy 0 takes the totals.
+    // The copies' sums: lane (cell, q) reads words 2q, 2q+1 of its cell in every copy (one 16-byte read each), adds the
+    // four 32-bit halves apart and clears the words for the next feature.  It owns bins 2q, 2q+1:
+    //   bin 2q   = low half of word 2q   + high half of word 2q-1 (lane q-1 of the quad, q = 0: word 7, lane q = 3)
+    //   bin 2q+1 = low half of word 2q+1 + high half of word 2q
     __builtin_amdgcn_wave_barrier();
     uint4 t = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -1035,21 +1043,14 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
       uint4* const w = reinterpret_cast<uint4*>(sums + cpy * PX_COPY_U64 + 2 * lane);
       const uint4 x = *w;
       t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
-      if (cpy) *w = make_uint4(0u, 0u, 0u, 0u);
+      *w = make_uint4(0u, 0u, 0u, 0u);
     }
-    *reinterpret_cast<uint4*>(sums + 2 * lane) = t;
-    __builtin_amdgcn_wave_barrier();
-    // lane (cell, q) owns bins 2q, 2q+1: even pair q = [2q | 2q+1], odd pair q-1 = [2q-1 | 2q], odd pair q = [2q+1 | 2q+2]
     {
-      const int cell = lane >> 2, q = lane & 3;
-      const uint32_t* const cw = reinterpret_cast<const uint32_t*>(sums + cell * 8);
-      const uint2 ev = *reinterpret_cast<const uint2*>(cw + 2 * q);
-      const uint32_t od_hi = cw[8 + 2 * ((q + 3) & 3) + 1], od_lo = cw[8 + 2 * q];
-      const float f0 = (float)(ev.x + od_hi) * rscale, f1 = (float)(ev.y + od_lo) * rscale;
+      const uint32_t prev_hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)t.w, 0x93 /* quad_perm:[3,0,1,2] */, 0xF, 0xF, true);
+      const float f0 = (float)(t.x + prev_hi) * rscale, f1 = (float)(t.z + t.y) * rscale;
       *reinterpret_cast<float2*>(&dl[wv][2 * lane]) = make_float2(f0, f1);
     }
     __builtin_amdgcn_wave_barrier();
-    *reinterpret_cast<uint4*>(sums + 2 * lane) = make_uint4(0u, 0u, 0u, 0u);
     float* dout = desc + (obase + oidx) * dim;
     float* hout = (HOST_MIRROR && dp.hdesc) ? dp.hdesc + (obase + oidx) * dim : nullptr;
     if (dp.half_sift) {  // des[k] += des[k+4], ProgramCU.cu:1782-1785: lane < 32 -> cell lane/2, k = 2 (lane & 1) + {0, 1}

@@ -828,9 +828,74 @@ static void compute_descriptor_pixel(const hess_cpu_ctx* c, const frec* rec, flo
   normalize_descriptor(c, d);
 }
 
+/* HESS_ORACLE_DESC_EXACT (oracle/hess_oracle.h): the reference's formula in double precision.  Same pixels, same
+ * window test, same weights as ComputeDescriptor_Kernel (ProgramCU.cu:1690-1790) cell by cell, and the normalisation
+ * of NormalizeDescriptor_Kernel (:1972-2054) -- every intermediate a double; inputs are the float record fields and
+ * the float (gradient, theta) plane. */
+static void compute_descriptor_exact(const hess_cpu_ctx* c, const frec* rec, float angle, const float* got,
+                                     int width, int height, float* d /* 128 or 64 */) {
+  const int half = c->p.half_sift;
+  const double kx = FIXED_TO_FLOAT(rec->x & 0x00FFFFFFu, 10);
+  const double ky = FIXED_TO_FLOAT(rec->y & 0x00FFFFFFu, 10);
+  const double kz = FIXED_TO_FLOAT(rec->z & 0x0000FFFFu, 8);
+  const double kw = angle;
+  const double spt = fabs(kz * (double)c->p.desc_window_factor);
+  const double s = sin(kw), co = cos(kw);
+  const float anglef_f = (angle > PI_D) ? (float)(angle - (2.0 * PI_D)) : angle, rpi_f = (float)(4.0 / PI_D);
+  const double cspt = co * spt, sspt = s * spt, crspt = co / spt, srspt = s / spt;
+  const double bsz = fabs(cspt) + fabs(sspt);
+  double out[128];
+  for (int bidx = 0; bidx < 16; bidx++) {
+    const int ix = bidx & 3, iy = bidx >> 2;
+    const double offx = ix - 1.5, offy = iy - 1.5;
+    const double ptx = cspt * offx - sspt * offy + kx, pty = cspt * offy + sspt * offx + ky;
+    const double xmin = fmax(1.5, floor(ptx - bsz) + 0.5), ymin = fmax(1.5, floor(pty - bsz) + 0.5);
+    const double xmax = fmin(width - 1.5, floor(ptx + bsz) + 0.5), ymax = fmin(height - 1.5, floor(pty + bsz) + 0.5);
+    double des[9];
+    for (int i = 0; i < 9; ++i) des[i] = 0.0;
+    for (double y = ymin; y <= ymax; y += 1.0) {
+      for (double x = xmin; x <= xmax; x += 1.0) {
+        const double dx = x - ptx, dy = y - pty;
+        const double nx = crspt * dx + srspt * dy, ny = crspt * dy - srspt * dx;
+        if (!(fabs(nx) < 1.0 && fabs(ny) < 1.0)) continue;
+        const float* cc = got + 2 * ((long)(int)y * width + (int)x);
+        const double dnx = nx + offx, dny = ny + offy;
+        const double weight = exp(-0.125 * (dnx * dnx + dny * dny)) * (1.0 - fabs(nx)) * (1.0 - fabs(ny)) * (double)cc[0];
+        /* the bin coordinate as the kernels form it, in float: which bin a sample falls into -- and whether it is the
+         * dropped floor(theta) == 8 case -- is a discrete decision every float order takes the same way */
+        float theta_f = (anglef_f - cc[1]) * rpi_f;
+        if (theta_f < 0) theta_f += 8.0f;
+        const double theta = theta_f;
+        const double fo = floor(theta);
+        const int fidx = (int)fo;
+        if (fidx >= 0 && fidx < 8) {
+          des[fidx] += (fo + 1.0 - theta) * weight;
+          des[fidx + 1] += (theta - fo) * weight;
+        } else if (fidx == 8 && c->p.dynamic_indexing) {
+          des[8] += (fo + 1.0 - theta) * weight;
+        }
+      }
+    }
+    des[0] += des[8];
+    if (half) for (int k = 0; k < 4; k++) out[bidx * 4 + k] = des[k] + des[k + 4];
+    else for (int k = 0; k < 8; k++) out[bidx * 8 + k] = des[k];
+  }
+  const int n = half ? 64 : 128;
+  if (c->p.normalize) {
+    for (int pass = 0; pass < 2; pass++) {
+      double sum = 0.0;
+      for (int j = 0; j < n; j++) sum += out[j] * out[j];
+      const double nrm = 1.0 / sqrt(sum);
+      for (int j = 0; j < n; j++) out[j] = pass == 0 ? fmin(0.2, out[j] * nrm) : out[j] * nrm;
+    }
+  }
+  for (int j = 0; j < n; j++) d[j] = (float)out[j];
+}
+
 static void compute_descriptor(const hess_cpu_ctx* c, int order, const frec* rec, float angle, const float* got,
                                int width, int height, float* d /* 128 or 64 */) {
   if (order == HESS_DESC_ORDER_PIXEL) { compute_descriptor_pixel(c, rec, angle, got, width, height, d); return; }
+  if (order == HESS_ORACLE_DESC_EXACT) { compute_descriptor_exact(c, rec, angle, got, width, height, d); return; }
   const float rpi = (float)(4.0 / PI_D);
   int half = c->p.half_sift;
   float kx = FIXED_TO_FLOAT(rec->x & 0x00FFFFFFu, 10);

@@ -45,6 +45,12 @@ typedef struct hess_cpu_ctx hess_cpu_ctx;
  *   0 = the CUDA path's rule (sample centres in [1.5, dim-1.5]; also the unpacked GLSL shaders')
  *   1 = the packed GLSL shaders' rule (box clamped to [2, dim-3], widened to whole 2x2 texels) */
 #define HESS_ORACLE_BORDER(p) ((p)->reserved[1])
+/* Analysis value of hess_params.descriptor_order, oracle only (hess_create refuses it): the reference's descriptor
+ * formula (ProgramCU.cu:1690-1790, per cell, + normalisation :1950-2054) evaluated in DOUBLE precision from the same
+ * float (gradient, theta) planes -- what every float summation order approximates.  The tests use it to say how far
+ * each declared order is from the formula itself: the reference's sequential float order carries its own rounding
+ * (the cell centres are rounded at the magnitude of the image coordinate: 1e-5 relative at x = 4000). */
+#define HESS_ORACLE_DESC_EXACT 3
 
 void hess_cpu_default_params(hess_params* p);
 hess_cpu_ctx* hess_cpu_create(const hess_params* params);

@@ -46,10 +46,10 @@ def test_bench_json_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
     kernels = {rf["kernel"].split(" (")[0].split(" /")[0], d["roofline_secondary"]["kernel"].split(" (")[0].split(" /")[0]}
     # a batch of three images is delivered by the copier thread: the descriptor launch does not mirror to the host
-    # (names as in a kernel trace: descriptor_kernel<host mirror, sequential order>)
-    assert kernels == {"gauss_kernel", "descriptor_kernel<false, false>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
+    # (names as in a kernel trace: descriptor_pixel_kernel<host mirror>, the default order's kernel)
+    assert kernels == {"gauss_kernel", "descriptor_pixel_kernel<false>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
     dk = rf if rf["kernel"].startswith("descriptor") else d["roofline_secondary"]
-    assert dk["with_host_mirror"]["kernel"] == "descriptor_kernel<true, false>" and dk["with_host_mirror"]["avg_launch_us"] > 0
+    assert dk["with_host_mirror"]["kernel"] == "descriptor_pixel_kernel<true>" and dk["with_host_mirror"]["avg_launch_us"] > 0
     assert dk["valu"]["peak"] == 1228.8 and 0 < dk["valu"]["frac"] < 1
     gk = rf if rf["kernel"].startswith("gauss") else d["roofline_secondary"]
     o0 = gk["octave0_launches"]  # the Gaussian launches of octave 0, timed apart: the bandwidth-bound part of the stage

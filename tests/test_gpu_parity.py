@@ -16,26 +16,45 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # BASELINE.json north_star: "keypoints/descriptors matching reference within 1e-4"
 # The product's default descriptor order (HESS_DESC_ORDER_PIXEL) is not the reference's summation order (include/hess_abi.h,
-# hess_params.descriptor_order); on every BASELINE config it is tied to the reference's sequential order
-# (ProgramCU.cu:1723-1774, the oracle's descriptor_order=1) by this tolerance on unit-norm descriptors (measured
-# <= 6e-6, most of it the sequential float order's own rounding: tests/test_descriptor_order.py):
-TOL_ORDER = 1e-5
+# hess_params.descriptor_order).  On every BASELINE config it is tied to the reference two ways:
+#   TOL_EXACT   to the reference's FORMULA (ProgramCU.cu:1690-1790 + :1950-2054) evaluated in double precision by the
+#               oracle (oracle/hess_oracle.h, HESS_ORACLE_DESC_EXACT) -- measured <= 2.5e-7 on configs[1], [2], [4];
+#   TOL_ORDER   to the reference's sequential FLOAT order (the oracle's descriptor_order=1).  That order carries its own
+#               rounding -- it rounds every cell centre at the magnitude of the image coordinate, 1e-5 relative at
+#               x = 4000 -- and is itself 6e-6 (1080p), 2.5e-6 (640x480), 1.6e-5 (4096^2) from the formula, so the
+#               distance between the two orders is that figure; the test bounds it by the sequential order's own
+#               distance to the formula + TOL_EXACT, and by TOL_ORDER overall (north star: 1e-4).
+TOL_EXACT = 1e-6
+TOL_ORDER = 3e-5
+HESS_ORACLE_DESC_EXACT = 3
 
 
 def _assert_tied_to_reference_order(g, imgs, kw, what, threads=16):
     """The context's results (already run on imgs, any descriptor order) against the oracle in the REFERENCE's
-    summation order: keypoints bitwise, descriptors within TOL_ORDER."""
-    o = OracleSession(threads=threads, keep_levels=False, descriptor_order=_abi.DESC_ORDER_SEQUENTIAL, **kw)
-    o.run(imgs)
-    worst = 0.0
+    summation order and against the reference's formula in double precision: keypoints bitwise, descriptors within
+    the tolerances above."""
+    worst = {"seq": 0.0, "exact": 0.0, "seq_exact": 0.0}
+    os_ = OracleSession(threads=threads, keep_levels=False, descriptor_order=_abi.DESC_ORDER_SEQUENTIAL, **kw)
+    oe = OracleSession(threads=threads, keep_levels=False, descriptor_order=HESS_ORACLE_DESC_EXACT, **kw)
+    os_.run(imgs)
+    oe.run(imgs)
     for b in range(len(imgs)):
         gk, gd = g.fetch(b)
-        ok, od = o.fetch(b)
-        assert gk.tobytes() == ok.tobytes(), f"{what}: img {b}: keypoints differ from the sequential-order oracle"
-        if od.size:
-            worst = max(worst, float(np.abs(gd.astype(np.float64) - od.astype(np.float64)).max()))
-    o.close()
-    assert worst <= TOL_ORDER, f"{what}: default order vs the reference's sequential order: max abs diff {worst}"
+        sk, sd = os_.fetch(b)
+        ek, ed = oe.fetch(b)
+        assert gk.tobytes() == sk.tobytes() == ek.tobytes(), f"{what}: img {b}: keypoints differ from the sequential-order oracle"
+        if sd.size:
+            ed = ed.astype(np.float64)
+            worst["seq"] = max(worst["seq"], float(np.abs(gd - sd.astype(np.float64)).max()))
+            worst["exact"] = max(worst["exact"], float(np.abs(gd - ed).max()))
+            worst["seq_exact"] = max(worst["seq_exact"], float(np.abs(sd - ed).max()))
+    os_.close()
+    oe.close()
+    if g.params.descriptor_order == _abi.DESC_ORDER_PIXEL:
+        assert worst["exact"] <= TOL_EXACT, f"{what}: distance to the reference's formula in double precision {worst}"
+        assert worst["seq"] <= min(TOL_ORDER, worst["seq_exact"] + TOL_EXACT), f"{what}: distance to the sequential float order {worst}"
+    else:  # a float order: within rounding of the sequential one (tests/test_descriptor_order.py: 1e-6), as far from the formula as it
+        assert worst["seq"] <= 1e-6 and worst["exact"] <= worst["seq_exact"] + 1e-6, f"{what}: {worst}"
     return worst
 
 
