@@ -63,9 +63,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[3]: 64 images over 8 GPUs)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images per GPU (0 = --batch: all distinct)")
-    ap.add_argument("--contexts", type=int, default=7, help="contexts (streams) pipelined per GPU (with the copier-thread delivery a "
-                    "context's stream idles while its results are copied; round 4, same call, 200 steps: 4: 16.5, 5: 17.2, 6: 17.5 - 18.1, "
-                    "7: 17.8 - 18.4, 8: 17.1, 9: 18.0, 10: 17.7, 11: 18.4, 13: 18.2 Gpix/s -- the streams share four hardware queues)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts (streams) pipelined per GPU; 0 = 6 on one GPU, 5 per rank for N > 1.  "
+                    "Round 5, same call, the driver's --steps 20 --warmup 5 / 200 steady steps, Gpix/s: 3: 18.4 - 20.0 / 21.8, 4: 18.9 - 19.2 / 20.6, "
+                    "5: 19.7 - 19.8 / 21.9, 6: 20.5 / 21.3 - 22.4, 7: 20.2 - 20.4 / 22.5, 8: 19.7 / 20.4 - 21.0, 9: 20.2 - 20.4 / 22.0, 11: 19.9 - 20.5 / 22.3 "
+                    "(the streams share four hardware queues).  N > 1: five contexts per rank keep a node of eight ranks at 40 copier "
+                    "threads / 40 streams and the node-shared result buffers near 1.2 GB for 3 % of one GPU's steady rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host and single-image legs")
@@ -148,7 +150,7 @@ def main():
 
     # Contexts used round-robin: while one batch's results travel to the host (and, for N > 1, are gathered over
     # RCCL), the next batches' kernels already run on the other contexts' streams.
-    nctx = max(1, args.contexts)
+    nctx = args.contexts if args.contexts > 0 else (6 if world == 1 else 5)
     order_kw = {"descriptor_order": args.desc_order} if args.desc_order >= 0 else {}
     def make_contexts():
         return [hessgpu_amd.HessContext(local_rank, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=TOPK,
@@ -219,7 +221,8 @@ def main():
                 in_files = sum(p["bytes"] for ps in allp for p in ps if not p["desc"].startswith("/dev/shm/"))
                 print(f"bench.py: node-shared result buffers: {tot / 1e6:.0f} MB for {world} rank(s) x {nctx} contexts "
                       f"({tot / 1e6 / max(1, world * nctx):.1f} MB each, sized by need); /dev/shm has {free_mb:.0f} MB free now; "
-                      f"{in_files / 1e6:.0f} MB of them in files instead (no room in /dev/shm)", file=sys.stderr)
+                      f"{in_files / 1e6:.0f} MB of them in files instead (no room in /dev/shm); per node: {world * nctx} streams, "
+                      f"{world * nctx} copier threads", file=sys.stderr)
                 for r, ps in enumerate(allp):
                     where = sorted({os.path.dirname(p["desc"]) for p in ps})
                     print(f"bench.py:   rank {r}: {sum(p['bytes'] for p in ps) / 1e6:.0f} MB in {', '.join(where)}", file=sys.stderr)
@@ -391,6 +394,7 @@ def main():
                 "workload": workload,
                 "images_per_gpu_per_step": B,
                 "pipelined_contexts_per_gpu": nctx,
+                "streams_and_copier_threads_per_node": world * nctx,
                 "descriptor_order": {0: "interleaved", 1: "sequential", 2: "pixel"}.get(desc_order, str(desc_order)),
                 "distinct_images_per_gpu": nd,
                 "features_per_image_mean": round(float(np.mean(counts)), 1),

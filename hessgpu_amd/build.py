@@ -111,6 +111,15 @@ def build_all(force=False, verbose=False):
                   "-lrccl", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"])
         if os.path.exists(exe):
             built.append(exe)
+        # bench.py's step loop in C++ (C ABI + HIP runtime, host code only)
+        src = os.path.join(apps_dir, "pipeline.cpp")
+        exe = os.path.join(bindir, "pipeline")
+        if os.path.exists(src) and (force or _newer([src, os.path.join(HERE, "..", "include", "hess_abi.h"), lib], exe)):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "..", "include"),
+                  "-I", "/opt/rocm/include", src, "-o", exe, "-L", HERE, "-lhessgpu", "-L", "/opt/rocm/lib", "-lamdhip64",
+                  "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"])
+        if os.path.exists(exe):
+            built.append(exe)
     if verbose:
         print("built:", *built)
     return built

@@ -8,6 +8,7 @@
 // Build: hipcc -O3 --offload-arch=gfx950 strided_streams.hip -o strided_streams
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 constexpr int W = 1920, H = 1080, B = 8, L = 5, ROWS = 24;
@@ -69,14 +70,22 @@ float timeit(F f) {
   return ms / 20.0f * 1000.0f;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const size_t n = (size_t)L * B * H * W;
   float *p, *q, *out;
   hipMalloc(&p, n * 4); hipMalloc(&q, (size_t)1 << 30); hipMalloc(&out, 64);
   hipMemset(p, 0, n * 4); hipMemset(q, 0, (size_t)1 << 30);
   const dim3 grid(((W / 128) * (H / ROWS) + 3) / 4, B);
   const double gb = (double)n * 4 / 1e9, gbh = gb * (ROWS + 2.0) / ROWS;
-  auto flush = [&] { hipMemsetAsync(q, 1, (size_t)1 << 30, 0); };  // evict the planes from the last-level cache between runs
+  // Evict the planes from the last-level cache between runs -- two ways (round 5): by a 1 GB FILL
+  // (round 4's form: it leaves the caches full of DIRTY lines, so the timed launch may be paying their write-back)
+  // or by a 1 GB READ pass (clean lines).  argv[1] = "read" selects the second.
+  const bool by_read = argc > 1 && !strcmp(argv[1], "read");
+  auto flush = [&] {
+    if (by_read) hipLaunchKernelGGL(flat, dim3(256 * 16), dim3(256), 0, 0, (const float4*)q, ((size_t)1 << 30) / 16, out);
+    else hipMemsetAsync(q, 1, (size_t)1 << 30, 0);
+  };
+  printf("eviction between the timed launches: 1 GB %s\n", by_read ? "READ pass (clean lines)" : "FILL (dirty lines)");
   printf("planes: %.1f MB (%.1f MB with the two halo rows per segment of %d)\n", gb * 1e3, gbh * 1e3, ROWS);
   float t;
   t = timeit([&] { flush(); });
