@@ -227,7 +227,9 @@ void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, flo
 
 // Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch);
+                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch,
+                         int first_block = 0, int nblocks = 0);  // (a range of the image's streaming workgroups; 0, 0 = all)
+bool extrema_streams(const Geom& g);  // the streaming scan (and with it the range form) applies to this geometry
 // Exclusive scan of the row counts per image, level totals, -tc level truncation
 // (GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278).
 void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt,

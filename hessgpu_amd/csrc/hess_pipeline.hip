@@ -29,8 +29,10 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <limits.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 
 #include "../../include/hess_abi.h"
@@ -201,6 +203,7 @@ struct hess_ctx {
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
+  bool early_scan = false;         // HESS_EARLY_SCAN: octave 0's extrema scan right behind octave 0's last pyramid launch (A/B switch)
   bool no_top_fusion = false;      // HESS_NO_TOP_FUSION: the top level is stored and its det-H made by a launch of its own (A/B switch)
   bool keep_levels = false;        // hess_debug_keep_levels: the top Gaussian level of every octave is written to HBM as well
   int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
@@ -330,6 +333,14 @@ int ensure_shared(hess_ctx* c, DevBuf& b, size_t bytes, char which) {
     const char* dir = getenv("HESS_SHARE_DIR");
     if (!dir || !dir[0]) dir = getenv("TMPDIR");
     if (!dir || !dir[0]) dir = "/tmp";
+    // the directory as an absolute path (a reader process may have another working directory), and a word of warning
+    // when it is not memory-backed: the DMA copies of every batch then dirty page-cache pages the kernel writes to disk
+    char absdir[PATH_MAX];
+    if (realpath(dir, absdir)) dir = absdir;
+    struct statfs sfs;
+    if (statfs(dir, &sfs) == 0 && sfs.f_type != 0x01021994 /* TMPFS_MAGIC */ && sfs.f_type != 0x858458f6 /* RAMFS_MAGIC */ &&
+        (c->p.verbose & 1))
+      fprintf(stderr, "hessgpu: shared result buffer %s goes to %s, which is not a tmpfs: expect disk write-back per batch\n", name + 1, dir);
     snprintf(path, sizeof(path), "%s%s", dir, name);
     (void)unlink(path);
     fd = open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -693,6 +704,24 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   c->stage_events = (c->p.verbose & 2) != 0;
   HIP_TRY(c, hipEventRecord(c->ev[0], st));
   const bool user_mode = !c->user_keys.empty();
+  DetectParams dp;
+  dp.thr = p.dog_threshold;
+  dp.thr0 = (p.subpixel ? 0.8f : 1.0f) * p.dog_threshold;                            // ProgramCU.cu:897
+  dp.edge = (p.edge_threshold + 1) * (p.edge_threshold + 1) / p.edge_threshold;      // ProgramCU.cu:913
+  dp.subpixel = p.subpixel;
+  Geom gx = g;  // the extrema scan's segment length
+  if (c->stream_rows > 0) set_stream_rows(gx, c->stream_rows);      // HESS_STREAM_ROWS (A/B switch; a multiple of 3)
+  else if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);        // one or two images: shorter segments, twice the wavefronts
+  // HESS_EARLY_SCAN=1 (A/B switch): octave 0's part of the extrema scan right behind the launch that completes octave 0's
+  // det-H planes, while the last of them may still be in the last-level cache, instead of after the whole pyramid
+  int scanned_blocks = 0;
+  auto early_scan = [&]() {
+    if (!c->early_scan || user_mode || batch < 3 || g.noct < 2 || !extrema_streams(gx) || !c->zero_filled || scanned_blocks) return;
+    double det_bytes = 4.0 * s.level_num * g.o[0].plane;
+    ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
+    scanned_blocks = gx.o[1].stream_base;
+    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch, 0, scanned_blocks);
+  };
   if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
   // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
   const bool direct_u8 = (format == HESS_FMT_LUM && pixtype == HESS_PIX_U8 && c->ds == 0 && c->has_taps0 &&
@@ -826,10 +855,14 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     }
     for (int l = 1; l <= s.level_max; l++) {
       if (l == 1 && deferred_o >= 0) {  // the previous octave's top level rides with this octave's level 1
-        const GaussJob ja = level_job(deferred_o, s.level_max), jb = level_job(o, 1);
-        ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max) + level_bytes(o, 1), deferred_o == 0 ? HESS_K_GAUSS_OCT0 : -1);
-        if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
-        else { launch_level(ja); launch_level(jb); }
+        const int top_o = deferred_o;
+        {
+          const GaussJob ja = level_job(top_o, s.level_max), jb = level_job(o, 1);
+          ProfScope ps(c, HESS_K_GAUSS, level_bytes(top_o, s.level_max) + level_bytes(o, 1), top_o == 0 ? HESS_K_GAUSS_OCT0 : -1);
+          if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
+          else { launch_level(ja); launch_level(jb); }
+        }
+        if (top_o == 0) early_scan();
         deferred_o = -1;
         continue;
       }
@@ -879,25 +912,17 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   }  // !(user_mode && on_current)
   if (user_mode) return enqueue_user(c);
   // ---- extrema + ordered list (DetectKeypointsEX part 2 + GenerateFeatureList) ----
-  DetectParams dp;
-  dp.thr = p.dog_threshold;
-  dp.thr0 = (p.subpixel ? 0.8f : 1.0f) * p.dog_threshold;                            // ProgramCU.cu:897
-  dp.edge = (p.edge_threshold + 1) * (p.edge_threshold + 1) / p.edge_threshold;      // ProgramCU.cu:913
-  dp.subpixel = p.subpixel;
   LimitParams lp;
   lp.method = p.truncate_method;
   lp.threshold = p.feature_count_threshold;
-  if (!c->zero_filled)  // overflow flags, row counts, histogram, masks (normally cleared by the det-H launch above)
+  if (!c->zero_filled)  // overflow flags, row counts, histogram, masks (normally cleared by octave 0's top-level launch)
     HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, c->zeroed_used, st));
   {
     // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
     double det_bytes = 0;
-    for (int o = 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
+    for (int o = scanned_blocks ? 1 : 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
-    Geom gx = g;
-    if (c->stream_rows > 0) set_stream_rows(gx, c->stream_rows);      // HESS_STREAM_ROWS (A/B switch; a multiple of 3)
-    else if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);        // one or two images: shorter segments, twice the wavefronts
-    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch);
+    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch, scanned_blocks, 0);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
   {
@@ -1338,7 +1363,7 @@ void copier_main(hess_ctx* c) {
         // (the pinned buffers hold the worst case unless that exceeds 512 MB: then they grow here, rarely)
         if (hk->bytes < total * sizeof(HostKeypoint) || (c->dim && hd->bytes < total * c->dim * 4)) {
           if (ensure(c, *hk, total * sizeof(HostKeypoint), true) || (c->dim && ensure(c, *hd, total * c->dim * 4, true))) {
-            snprintf(msg, sizeof(msg), "pinned result buffers: allocation failed (copier)");
+            snprintf(msg, sizeof(msg), "pinned result buffers: %s (copier)", c->err.empty() ? "allocation failed" : c->err.c_str());
             rc = HESS_ERR_NOMEM;
           }
         }
@@ -1623,6 +1648,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
   c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
   c->no_top_fusion = getenv("HESS_NO_TOP_FUSION") != nullptr;
+  c->early_scan = getenv("HESS_EARLY_SCAN") != nullptr;
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
@@ -2037,6 +2063,11 @@ int hess_share_results(hess_ctx* c, const char* name) {
     c->share = name;  // (nothing thrown crosses the C ABI)
   } catch (...) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
   (void)shm_unlink(dir);
+  for (unsigned gen = 1; gen <= 64; gen++) {  // buffers a crashed job of the same name left behind (the generations start at 1)
+    char stale[256];
+    snprintf(stale, sizeof(stale), "/%s.k%u", name, gen); (void)shm_unlink(stale);
+    snprintf(stale, sizeof(stale), "/%s.d%u", name, gen); (void)shm_unlink(stale);
+  }
   const int fd = shm_open(dir, O_CREAT | O_EXCL | O_RDWR, 0600);
   if (fd < 0) { set_err(c, "shm_open(%s) failed: %s", dir, strerror(errno)); c->share.clear(); return HESS_ERR_NOMEM; }
   void* m = ftruncate(fd, 4096) == 0 ? mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;

@@ -401,17 +401,18 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf
 
 template <int DOG>
 __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParams dp, const float* deth,
-                                                             unsigned long long* rowmask, int* rowcnt) {
+                                                             unsigned long long* rowmask, int* rowcnt, int block0) {
   constexpr int NLV = DOG + 2;
   constexpr int NC = kStreamCols;  // columns per lane
   __shared__ uint32_t queue[4][SX_QCAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
+  const int blk = (int)blockIdx.x + block0;  // (a launch may cover a range of the image's workgroups: launch_extrema_mark)
   int o = 0;
   for (int k = 1; k < g.noct; k++)
-    if (g.o[k].stream_base <= (int)blockIdx.x) o = k;
+    if (g.o[k].stream_base <= blk) o = k;
   const OctGeom& og = g.o[o];
-  const int task = ((int)blockIdx.x - og.stream_base) * 4 + wv;
+  const int task = (blk - og.stream_base) * 4 + wv;
   const int seg = task / og.strips, strip = task - seg * og.strips;
   const int ys = seg * g.stream_rows;
   if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
@@ -1143,20 +1144,25 @@ void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, flo
                      reinterpret_cast<uint4*>(zero), (long long)(zero_bytes / 16));
 }
 
+bool extrema_streams(const Geom& g) { return g.dog <= 5 && g.o[0].wa < (1 << 14) && g.o[0].h < (1 << 14); }
+
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch) {
+                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch, int first_block, int nblocks) {
   (void)gauss;
   // rowcnt and rowmask arrive zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
   // streaming scan (sets mask bits with atomics); its candidate queue packs row and column in 14 bits each
-  if (g.dog <= 5 && g.o[0].wa < (1 << 14) && g.o[0].h < (1 << 14)) {
+  if (extrema_streams(g)) {
     unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);
-    const dim3 grid(g.nstream, batch), blk(256);
+    // (first_block, nblocks): a range of the image's workgroups -- octaves back to back, g.o[].stream_base -- or all of them
+    const int b0 = first_block > 0 ? first_block : 0, nb = nblocks > 0 ? nblocks : g.nstream - b0;
+    if (nb <= 0) return;
+    const dim3 grid(nb, batch), blk(256);
     switch (g.dog) {
-      case 1: hipLaunchKernelGGL(extrema_stream_kernel<1>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
-      case 2: hipLaunchKernelGGL(extrema_stream_kernel<2>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
-      case 3: hipLaunchKernelGGL(extrema_stream_kernel<3>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
-      case 4: hipLaunchKernelGGL(extrema_stream_kernel<4>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
-      default: hipLaunchKernelGGL(extrema_stream_kernel<5>, grid, blk, 0, st, g, dp, deth, rm, rowcnt); break;
+      case 1: hipLaunchKernelGGL(extrema_stream_kernel<1>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
+      case 2: hipLaunchKernelGGL(extrema_stream_kernel<2>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
+      case 3: hipLaunchKernelGGL(extrema_stream_kernel<3>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
+      case 4: hipLaunchKernelGGL(extrema_stream_kernel<4>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
+      default: hipLaunchKernelGGL(extrema_stream_kernel<5>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
     }
     return;
   }
