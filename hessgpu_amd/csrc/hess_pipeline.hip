@@ -113,6 +113,7 @@ struct Copier {
   bool hsa_ready = false, hsa_failed = false;
   hsa_agent_t gpu_agent{}, cpu_agent{};
   uint32_t engine = 0;          // hsa_amd_sdma_engine_id_t bit, 0 = let ROCr choose
+  uint32_t engine_in = 0;       // the same for the host->device upload of pinned pixels
   hsa_signal_t sig{}, sig2{};   // one completion signal per copy in flight (keypoints, descriptors), each armed with 1: tools that
                                 // interpose on ROCr (rocprofv3 --memory-copy-trace) expect exactly that of a copy's signal
   // A job that begins with the batch's pixels still on their way (hess_submit_host, pinned input): the upload is an
@@ -1214,7 +1215,17 @@ bool copier_hsa_setup(hess_ctx* c) {
     for (int i = 0; i < k; i++) m &= m - 1;
     cp.engine = m & (~m + 1);
   }
+  // ... and an engine of the host->device set for the pixel uploads (left to ROCr, an upload sometimes lands on an engine
+  // that copies at a quarter of the rate: the host-to-host figure varied 15 - 21 Gpix/s from run to run)
+  uint32_t pref_in = 0;
+  if (hsa_amd_memory_get_preferred_copy_engine(cp.gpu_agent, cp.cpu_agent, &pref_in) == HSA_STATUS_SUCCESS && pref_in) {
+    const int n = __builtin_popcount(pref_in), k = g_copier_count.load() % n;
+    uint32_t m = pref_in;
+    for (int i = 0; i < k; i++) m &= m - 1;
+    cp.engine_in = m & (~m + 1);
+  }
   if (const char* e = getenv("HESS_COPIER_ENGINE")) cp.engine = (uint32_t)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("HESS_UPLOAD_ENGINE")) cp.engine_in = (uint32_t)strtoul(e, nullptr, 0);
   cp.hsa_failed = false;
   cp.hsa_ready = true;
   return true;
@@ -1842,7 +1853,13 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
         (cp.have_sig_in || hsa_signal_create(1, 0, nullptr, &cp.sig_in) == HSA_STATUS_SUCCESS)) {
       cp.have_sig_in = true;
       hsa_signal_store_relaxed(cp.sig_in, 1);
-      if (hsa_amd_memory_async_copy(c->stage.p, cp.gpu_agent, pixels, pi.agentOwner, bytes, 0, nullptr, cp.sig_in) == HSA_STATUS_SUCCESS) {
+      hsa_status_t up = cp.engine_in
+          ? hsa_amd_memory_async_copy_on_engine(c->stage.p, cp.gpu_agent, pixels, pi.agentOwner, bytes, 0, nullptr, cp.sig_in,
+                                                (hsa_amd_sdma_engine_id_t)cp.engine_in, false)
+          : HSA_STATUS_ERROR;
+      if (up != HSA_STATUS_SUCCESS)  // no engine chosen, or busy / not available: let ROCr choose
+        up = hsa_amd_memory_async_copy(c->stage.p, cp.gpu_agent, pixels, pi.agentOwner, bytes, 0, nullptr, cp.sig_in);
+      if (up == HSA_STATUS_SUCCESS) {
         c->last_input_bytes = bytes;
         *c->pend = PendingRun{c->stage.p, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, false};
         {

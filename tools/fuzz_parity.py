@@ -50,8 +50,12 @@ def main():
             kw["first_octave"] = 1
         if rng.rand() < 0.2:
             kw["subpixel"] = 0
-        if rng.rand() < 0.3:
-            kw["descriptor_order"] = 1    # the reference's sequential summation order (default: interleaved)
+        if rng.rand() < 0.4:
+            kw["descriptor_order"] = int(rng.choice([0, 1]))    # interleaved / the reference's sequential order (default: pixel raster)
+        if rng.rand() < 0.15:
+            kw["dynamic_indexing"] = 1
+        if rng.rand() < 0.15:
+            kw["normalize"] = 0
         g = hessgpu_amd.HessContext(0, **kw)
         o = OracleSession(threads=16, **kw)
         try:
