@@ -32,7 +32,7 @@ def main():
     steps = sum(int(r["launches"]) for r in scan)
     if steps <= 0:
         raise SystemExit("make_profile_json: no extrema scan launches in counters.csv: cannot tell how many steps the pass ran")
-    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_tail_kernel")))
+    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_tail_kernel")))
     traffic["valu_insts_per_image"] = round(gv / (steps * batch), 1)
     traffic["valu_insts_steps_in_pass"] = steps
     if not (1.0e6 < traffic["valu_insts_per_image"] < 1.0e8):   # a 1080p pyramid is 1.5e7 - 2.5e7 vector instructions
@@ -96,8 +96,11 @@ def extrema_table(d, tag, rows, traffic):
     if us:
         lines.append(f"| kernel time (GRBM pass) / effective clock | {us:.1f} us / {clock[k]['effective_clock_ghz']} GHz | |")
     lines += ["", "Verdict: the wavefronts wait (s_waitcnt) for two thirds of their time and issue vector instructions for a fifth of it at "
-              "three wavefronts per SIMD: the scan is bound by memory, not by instruction issue.  What kind of memory bound, and "
-              "the experiments that separate the readings: profiles/r04_experiments/extrema_scan.txt, profiles/r04_strided_streams.txt.", ""]
+              "three wavefronts per SIMD: the scan is bound by memory, not by instruction issue.  What kind of memory bound: its "
+              "access pattern alone runs at 5.3 - 5.6 TB/s when the caches were evicted by a READ pass and at 3.0 TB/s when they "
+              "were evicted by a FILL -- the scan pays the write-back of the dirty lines its predecessors (the pyramid launches) "
+              "left in the last-level cache (profiles/r05_strided_streams.txt; round 4's reading, a cold pass, was the fill form "
+              "only: profiles/r04_strided_streams.txt, profiles/r04_experiments/extrema_scan.txt).", ""]
     open(os.path.join(ROOT, "profiles", f"{tag}_extrema_counters.md"), "w").write("\n".join(lines))
 
 
@@ -138,7 +141,7 @@ def kernel_stats_top(d, tag, bench):
                     "achieved": round(b / avg_s / 1e9, 1), "frac": round(b / avg_s / 1e9 / 8000.0, 4),
                     "hipevents_avg_launch_us_same_run": e["avg_launch_us"]})
     else:  # one instantiation of the Gaussian kernel leads the table: price the whole family (all its rows) instead
-        fam = [x for x in rows if short(x["Name"]).startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_tail_kernel"))]
+        fam = [x for x in rows if short(x["Name"]).startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_tail_kernel"))]
         tot_s = sum(float(x["TotalDurationNs"]) for x in fam) * 1e-9
         calls = sum(int(x["Calls"]) for x in fam)
         per_step = max(1, round(e["ms_per_step"] * 1e3 / e["avg_launch_us"]))  # Gaussian launches per step (bench line)
