@@ -127,7 +127,8 @@ def kernel_stats_top(d, tag, bench):
     name = short(r["Name"])
     avg_s = float(r["AverageNs"]) * 1e-9
     entries = [bench.get("roofline"), bench.get("roofline_secondary")]
-    e = next((x for x in entries if x and x["kernel"].split(" (")[0].startswith(name.split("<")[0])), None)
+    key = "gauss" if name.startswith("gauss") else name.split("<")[0]   # (any Gaussian instantiation stands for the family's entry)
+    e = next((x for x in entries if x and x["kernel"].split(" (")[0].startswith(key)), None)
     if e is None:
         return None
     out = {
