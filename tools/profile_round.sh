@@ -9,8 +9,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics, single stream (averages comparable with bench.py's hipEvent roofline leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ctx1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > $OUT/bench_ctx1.json 2> $OUT/bench_ctx1.err
-# 2. kernel statistics, default pipelined contexts (seven since round 4)
+# 2. kernel statistics, default pipelined contexts (six since round 5)
 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-host-leg --no-api-leg --no-configs4 > $OUT/bench_ctxd.json 2> $OUT/bench_ctxd.err
+# 2b. the pipelined steps ALONE under the lightest trace (no statistics, no copy trace, no single-stream legs in the run):
+#     what the overlap / idle summary is taken from (round 5: with the roofline leg's single-stream steps in the same trace
+#     the "idle share" read 15 %; the pipelined part alone is 1 % idle)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_pipelined -- python3 $R/bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-host-leg --no-api-leg --no-configs4 --no-profile --no-steady > /dev/null 2> $OUT/trace_pipelined.err
 # 3./4. HBM traffic counters, one pass each
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-steady --no-host-leg --no-api-leg --no-configs4 --contexts 1 > /dev/null 2> $OUT/pmc_write.err
@@ -25,7 +29,7 @@ python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.jso
 python3 $R/tools/profile_clock_summary.py $OUT > $OUT/clock.csv 2> $OUT/clock.err || true
 # concurrency summaries of the two kernel traces (before the traces are deleted)
 python3 $R/tools/trace_overlap.py $OUT/stats_ctx1 > $OUT/overlap_ctx1.txt 2>&1 || true
-python3 $R/tools/trace_overlap.py $OUT/stats_default > $OUT/overlap_default.txt 2>&1 || true
+python3 $R/tools/trace_overlap.py $OUT/trace_pipelined > $OUT/overlap_default.txt 2>&1 || true
 # unprofiled bench lines on the same box: the default line and batches of 16
 cd $R
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err

@@ -6,6 +6,8 @@
 Over the steady part of the trace (the first `skip_fraction`, default 0.3, of the dispatches is dropped): wall time,
 time with at least one kernel running, mean number of kernels in flight, and per kernel the summed duration next to
 its share of the wall time -- set against a single-stream trace this shows which kernels stretch when they overlap.
+Then the IDLE intervals (no kernel in flight): how they are distributed by length, and which kernel ended before / which
+started after the ones that carry the idle time (round 5: where do the pipelined device's gaps come from?).
 """
 import collections
 import csv
@@ -25,12 +27,12 @@ def main():
     rows = []
     for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?"), r.get("Stream_Id", r.get("Thread_Id", "?"))))
     rows.sort()
     rows = rows[int(len(rows) * skip):]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     ev = []
-    for s, e, _ in rows:
+    for s, e, *_ in rows:
         ev.append((s, 1)); ev.append((e, -1))
     ev.sort()
     busy = 0; depth = 0; last = t0; area = 0
@@ -45,11 +47,32 @@ def main():
     print(f"dispatches {len(rows)}  wall {wall/1e6:.3f} ms  busy(>=1 kernel) {busy/1e6:.3f} ms ({busy/wall:.3f})  mean kernels in flight {area/wall:.2f}")
     print("time share by kernels in flight:", {k: round(v / wall, 3) for k, v in sorted(hist.items())})
     per = collections.defaultdict(lambda: [0, 0])
-    for s, e, n in rows:
+    for s, e, n, *_ in rows:
         per[n][0] += e - s; per[n][1] += 1
     print("kernel,calls,sum_ms,avg_us,sum/wall")
     for n, (tot, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
         print(f"{n},{c},{tot/1e6:.3f},{tot/c/1e3:.2f},{tot/wall:.3f}")
+    # idle intervals: sweep the dispatches in start order, keep the running maximum of the end times
+    gaps = []
+    cur_end, cur = rows[0][1], rows[0]
+    for r in rows[1:]:
+        if r[0] > cur_end:
+            gaps.append((r[0] - cur_end, cur, r))
+        if r[1] > cur_end:
+            cur_end, cur = r[1], r
+    idle = sum(g[0] for g in gaps)
+    print(f"idle intervals: {len(gaps)}, {idle/1e6:.3f} ms in all ({idle/wall:.3f} of the wall time)")
+    bins = [(0, 2e3), (2e3, 5e3), (5e3, 10e3), (10e3, 20e3), (20e3, 50e3), (50e3, 1e12)]
+    for lo, hi in bins:
+        sel = [g for g in gaps if lo <= g[0] < hi]
+        print(f"  {lo/1e3:5.0f} - {hi/1e3 if hi < 1e11 else float('inf'):5.0f} us: {len(sel):5d} intervals, {sum(g[0] for g in sel)/1e6:8.3f} ms")
+    pair = collections.defaultdict(lambda: [0, 0, 0])
+    for g, a, b in gaps:
+        k = (a[2], b[2], "same queue" if a[3] == b[3] else "other queue")
+        pair[k][0] += g; pair[k][1] += 1
+    print("idle time by (kernel that ended before, kernel that started after, queue): total ms, intervals, mean us")
+    for k, (tot, c, _) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"  {tot/1e6:7.3f} ms {c:5d} x {tot/c/1e3:6.1f} us   {k[0]} -> {k[1]} ({k[2]})")
 
 
 if __name__ == "__main__":
