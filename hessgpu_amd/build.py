@@ -45,6 +45,20 @@ def _run(cmd):
     return r
 
 
+def _jpeg_flags():
+    """libjpeg's header, if one is installed next to its shared library (siftgpu_api.cpp decodes JPEG files through the
+    library looked up at run time, but needs the version's own struct layout at compile time).  -idirafter: the directory
+    is searched LAST, so it adds jpeglib.h and nothing that a system directory provides."""
+    for prefix in ("/usr", "/usr/local", "/opt/conda"):
+        inc = os.path.join(prefix, "include")
+        if os.path.exists(os.path.join(inc, "jpeglib.h")):
+            libdirs = [d for d in (os.path.join(prefix, "lib"), os.path.join(prefix, "lib", "x86_64-linux-gnu"), os.path.join(prefix, "lib64"))
+                       if any(f.startswith("libjpeg.so") for f in (os.listdir(d) if os.path.isdir(d) else []))]
+            if libdirs:
+                return ["-idirafter", inc, f'-DHESS_JPEG_LIBDIR="{libdirs[0]}"']
+    return []
+
+
 def build_variant(name, extra_flags, verbose=False):
     """Developer A/B builds: tools/_variants/<name>/libhessgpu.so compiled with extra flags (e.g. -DHESS_DESC_WAVES=6);
     select it at run time with HESS_LIB=<path>.  Not part of the product build."""
@@ -88,8 +102,8 @@ def build_all(force=False, verbose=False):
         api = os.path.join(HERE, "libsiftgpu.so")
         api_hdr = os.path.join(HERE, "..", "include", "SiftGPU.h")
         if force or _newer([api_src, api_hdr] + headers, api) or jobs:
-            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include"),
-                  api_src, "-o", api, "-L", HERE, "-lhessgpu", "-ldl", "-Wl,-rpath,$ORIGIN"])
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include")] + _jpeg_flags() +
+                 [api_src, "-o", api, "-L", HERE, "-lhessgpu", "-ldl", "-Wl,-rpath,$ORIGIN"])
         built.append(api)
         apps_dir = os.path.join(HERE, "..", "apps")
         bindir = os.path.join(HERE, "bin")

@@ -177,6 +177,107 @@ int load_png(const char* path, std::vector<unsigned char>& out, int& w, int& h) 
   return ch == 1 ? HESS_FMT_LUM : ch == 2 ? HESS_FMT_LUM_ALPHA : ch == 3 ? HESS_FMT_RGB : HESS_FMT_RGBA;
 }
 
+// JPEG files (the reference's data/*.jpg, read there by DevIL: GLTexImage.cpp:1117-1158) through libjpeg, looked up at
+// RUN time like libpng above.  libjpeg's decompress object is a large struct whose layout depends on the library version,
+// so this part is only compiled where the library's own header is on the include path (the build adds the directory of
+// one whose shared library it finds: hessgpu_amd/build.py), and it asks for the library OF THAT VERSION by name; the
+// library checks version and struct size itself (jpeg_CreateDecompress) and every error comes back through error_exit ->
+// longjmp.  Grey files are handed on as luminance, everything else as RGB.  Returns 0: not a JPEG file; -1: a JPEG file
+// that cannot be read (library missing or decode error, message on stderr); else the HESS_FMT_*.
+#if defined(__has_include)
+#if __has_include(<jpeglib.h>)
+#define HESS_HAVE_JPEGLIB 1
+#endif
+#endif
+#ifdef HESS_HAVE_JPEGLIB
+}  // namespace
+#include <csetjmp>
+extern "C" {
+#include <jpeglib.h>
+}
+namespace {
+struct JpegErr {
+  jpeg_error_mgr pub;
+  jmp_buf jb;
+  char msg[JMSG_LENGTH_MAX];
+};
+void jpeg_fail(j_common_ptr cinfo) {
+  JpegErr* e = reinterpret_cast<JpegErr*>(cinfo->err);
+  (*cinfo->err->format_message)(cinfo, e->msg);
+  longjmp(e->jb, 1);
+}
+#define HESS_STR2(x) #x
+#define HESS_STR(x) HESS_STR2(x)
+#endif
+int load_jpeg(const char* path, std::vector<unsigned char>& out, int& w, int& h) {
+  unsigned char sig[3] = {0};
+  FILE* f = fopen(path, "rb");
+  if (!f) return 0;
+  const bool is_jpeg = fread(sig, 1, 3, f) == 3 && sig[0] == 0xFF && sig[1] == 0xD8 && sig[2] == 0xFF;
+  if (!is_jpeg) { fclose(f); return 0; }
+#ifndef HESS_HAVE_JPEGLIB
+  fclose(f);
+  std::cerr << "JPEG file, but this build was made without libjpeg's header: " << path << "\n";
+  return -1;
+#else
+  rewind(f);
+  // the library whose header this was compiled against: libjpeg.so.<major> (IJG 9: libjpeg.so.9, libjpeg-turbo's
+  // version-8 emulation: libjpeg.so.8), also beside the header's own installation
+  static void* lib = [] {
+    const char* names[] = {"libjpeg.so." HESS_STR(JPEG_LIB_VERSION_MAJOR),
+#ifdef HESS_JPEG_LIBDIR
+                           HESS_JPEG_LIBDIR "/libjpeg.so." HESS_STR(JPEG_LIB_VERSION_MAJOR),
+#endif
+                           nullptr};
+    for (const char** n = names; *n; n++)
+      if (void* l = dlopen(*n, RTLD_LAZY | RTLD_LOCAL)) return l;
+    return (void*)nullptr;
+  }();
+#define HESS_JSYM(name) static decltype(&::name) p_##name = lib ? (decltype(&::name))dlsym(lib, #name) : nullptr
+  HESS_JSYM(jpeg_std_error); HESS_JSYM(jpeg_CreateDecompress); HESS_JSYM(jpeg_stdio_src); HESS_JSYM(jpeg_read_header);
+  HESS_JSYM(jpeg_start_decompress); HESS_JSYM(jpeg_read_scanlines); HESS_JSYM(jpeg_finish_decompress);
+  HESS_JSYM(jpeg_destroy_decompress);
+#undef HESS_JSYM
+  if (!p_jpeg_std_error || !p_jpeg_CreateDecompress || !p_jpeg_stdio_src || !p_jpeg_read_header || !p_jpeg_start_decompress ||
+      !p_jpeg_read_scanlines || !p_jpeg_finish_decompress || !p_jpeg_destroy_decompress) {
+    fclose(f);
+    std::cerr << "JPEG file, but libjpeg.so." HESS_STR(JPEG_LIB_VERSION_MAJOR) " is not available at run time: " << path << "\n";
+    return -1;
+  }
+  jpeg_decompress_struct cinfo;
+  JpegErr err;
+  memset(&cinfo, 0, sizeof(cinfo));
+  cinfo.err = p_jpeg_std_error(&err.pub);
+  err.pub.error_exit = jpeg_fail;
+  volatile int fmt = -1;
+  if (setjmp(err.jb)) {  // every libjpeg error ends here (incl. a version / struct-size mismatch)
+    std::cerr << "libjpeg: " << err.msg << ": " << path << "\n";
+    p_jpeg_destroy_decompress(&cinfo);
+    fclose(f);
+    return -1;
+  }
+  p_jpeg_CreateDecompress(&cinfo, JPEG_LIB_VERSION, sizeof(cinfo));
+  p_jpeg_stdio_src(&cinfo, f);
+  p_jpeg_read_header(&cinfo, TRUE);
+  const bool grey = cinfo.jpeg_color_space == JCS_GRAYSCALE;
+  cinfo.out_color_space = grey ? JCS_GRAYSCALE : JCS_RGB;
+  p_jpeg_start_decompress(&cinfo);
+  const int ch = (int)cinfo.output_components;
+  if (ch != (grey ? 1 : 3)) { strcpy(err.msg, "unexpected number of output components"); longjmp(err.jb, 1); }
+  w = (int)cinfo.output_width; h = (int)cinfo.output_height;
+  out.assign((size_t)w * h * ch, 0);  // (bad_alloc: the class has no exception boundary above RunSIFT either)
+  while (cinfo.output_scanline < cinfo.output_height) {
+    JSAMPROW row = out.data() + (size_t)cinfo.output_scanline * w * ch;
+    p_jpeg_read_scanlines(&cinfo, &row, 1);
+  }
+  p_jpeg_finish_decompress(&cinfo);
+  p_jpeg_destroy_decompress(&cinfo);
+  fclose(f);
+  fmt = grey ? HESS_FMT_LUM : HESS_FMT_RGB;
+  return fmt;
+#endif
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -324,7 +425,7 @@ void SiftGPU::PrintUsage() {
                "-dint                                    ... as four interleaved partial sums (default: one pass over the pixels,\n"
                "                                         fixed-point sums; include/hess_abi.h, HESS_DESC_ORDER_*)\n"
                "                                         (default: four interleaved partial sums, 16 % faster, equal within 1e-6)\n"
-               "Image files: PGM / PPM (P2 P3 P5 P6), and PNG when libpng16.so.16 is present at run time -- this build has no\n"
+               "Image files: PGM / PPM (P2 P3 P5 P6); PNG when libpng16.so.16, JPEG when libjpeg is present at run time -- this build has no\n"
                "DevIL; decode JPEG in the caller and hand the pixels to RunSIFT(width, height, data, gl_format, gl_type).\n";
 }
 
@@ -591,13 +692,16 @@ int SiftGPU::RunSIFT() {  // SiftGPU.cpp:317-415
   if (_image_loaded == 0) {
     const int png = load_png(_imgpath, im->pixels, im->w, im->h);
     if (png < 0) return 0;
-    if (png > 0) {
-      im->fmt = png;
+    const int jpg = png == 0 ? load_jpeg(_imgpath, im->pixels, im->w, im->h) : 0;
+    if (jpg < 0) return 0;
+    if (png > 0 || jpg > 0) {
+      im->fmt = png > 0 ? png : jpg;
     } else if (load_pnm(_imgpath, im->pixels, im->w, im->h)) {
       im->fmt = HESS_FMT_LUM;
     } else {
-      std::cerr << "Unable to open image (this build reads PGM / PPM and, with libpng16 present at run time, PNG; decode "
-                   "JPEG in the caller and use RunSIFT(width, height, data, gl_format, gl_type)): " << _imgpath << "\n";
+      std::cerr << "Unable to open image (this build reads PGM / PPM and, with libpng16 / libjpeg present at run time, PNG "
+                   "and JPEG; other formats: decode in the caller and use RunSIFT(width, height, data, gl_format, gl_type)): "
+                << _imgpath << "\n";
       return 0;
     }
     im->pix = HESS_PIX_U8;
@@ -834,3 +938,17 @@ extern "C" int siftgpu_get_params(SiftGPU* s, void* out) {
   return 0;
 }
 extern "C" int siftgpu_descriptor_dim(SiftGPU* s) { return s ? Peek::impl(s)->dim : -1; }
+
+// Test hook: decode an image file as RunSIFT(path) would (PNG, JPEG, PNM), without a device.  Returns the HESS_FMT_* of
+// the decoded pixels (8 bits per channel) or <= 0; *w, *h are set; the pixels are copied when they fit `cap` bytes.
+extern "C" int siftgpu_debug_load_image(const char* path, unsigned char* out, size_t cap, int* w, int* h) {
+  std::vector<unsigned char> px;
+  int iw = 0, ih = 0, fmt = load_png(path, px, iw, ih);
+  if (fmt == 0) fmt = load_jpeg(path, px, iw, ih);
+  if (fmt == 0 && load_pnm(path, px, iw, ih)) fmt = HESS_FMT_LUM;
+  if (fmt <= 0) return fmt;
+  if (w) *w = iw;
+  if (h) *h = ih;
+  if (out && px.size() <= cap) memcpy(out, px.data(), px.size());
+  return fmt;
+}

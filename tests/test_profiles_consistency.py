@@ -29,7 +29,8 @@ def test_gauss_traffic_is_plausible():
 
 def test_descriptor_counters_are_plausible():
     d = _j("descriptor_counters.json")
-    assert 3.0e3 < d["valu_insts_per_feature"] < 1.2e4
+    # (round 4's cell-by-cell kernel: 5.6e3; the pixel raster of round 5: 2.7e3)
+    assert 1.5e3 < d["valu_insts_per_feature"] < 1.2e4
     assert 0.0 < d["wave_time_issuing_valu"] < 1.0 and 0.0 < d["wave_time_waiting"] < 1.0
     assert d["wave_time_issuing_valu"] + d["wave_time_waiting"] + d["wave_time_issue_stalled"] <= 1.0
     assert 0.3 < d["hbm_bytes_per_launch"] / d["algorithmic_bytes_per_launch"] < 2.0
@@ -44,7 +45,8 @@ def test_kernel_stats_top_is_the_top_row_of_the_committed_table():
     rows = [r for r in csv.DictReader(open(os.path.join(P, m.group(1)))) if "hess::" in r["Name"]]
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     name = re.sub(r"\(.*", "", rows[0]["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("hess::", ""))
-    assert top["kernel"].startswith(name.split("<")[0])
+    # (an instantiation of the Gaussian kernel at the top stands for the family's entry, which names it)
+    assert top["kernel"].startswith(name.split("<")[0]) or (name.startswith("gauss") and top["kernel"].startswith("gauss") and name in top["kernel"])
     if top["kernel"] == name:
         assert abs(top["avg_launch_us"] - float(rows[0]["AverageNs"]) / 1e3) < 0.05
         assert abs(top["achieved"] - top["algorithmic_bytes_per_launch"] / (top["avg_launch_us"] * 1e-6) / 1e9) < 1.0

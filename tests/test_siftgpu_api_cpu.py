@@ -94,3 +94,41 @@ def test_no_device_no_context():
     import numpy as np
     assert s.run(np.zeros((32, 32), np.uint8), siftgpu_lib.GL_LUMINANCE, siftgpu_lib.GL_UNSIGNED_BYTE) == 0
     s.close()
+
+
+def test_jpeg_decoding_hook():
+    """The file loader of RunSIFT(path) without a device (siftgpu_debug_load_image): data/640-1.jpg through libjpeg looked
+    up at run time, against PIL's decode of the same file (decoders differ in chroma up-sampling: sub-level mean difference)."""
+    import ctypes as C
+    import os
+
+    import numpy as np
+
+    import fixtures
+    import siftgpu_lib
+
+    L = siftgpu_lib.lib()
+    L.siftgpu_debug_load_image.restype = C.c_int
+    L.siftgpu_debug_load_image.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    buf = np.zeros(640 * 480 * 3, dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    fmt = L.siftgpu_debug_load_image(os.path.join(fixtures._DATA, "640-1.jpg").encode(), buf.ctypes.data, buf.size, C.byref(w), C.byref(h))
+    if fmt == -1:
+        import pytest
+        pytest.skip("no libjpeg of the compiled-in version at run time (or the build found no jpeglib.h)")
+    assert fmt == 3 and (w.value, h.value) == (640, 480)          # HESS_FMT_RGB
+    ref = fixtures.load_rgb("640-1.jpg").astype(np.int32)
+    got = buf.reshape(480, 640, 3).astype(np.int32)
+    assert np.abs(got - ref).mean() < 1.5
+    # a PNG and a PGM through the same hook
+    big = np.zeros(2048 * 2048 * 4, dtype=np.uint8)
+    assert L.siftgpu_debug_load_image(os.path.join(fixtures._DATA, "blobs.png").encode(), big.ctypes.data, big.size, C.byref(w), C.byref(h)) in (1, 2, 3, 4)
+    # (box.pgm carries a "# CREATOR" comment line, which the reference's PNM loader does not accept either: GLTexImage.cpp:1164)
+    assert L.siftgpu_debug_load_image(os.path.join(fixtures._DATA, "box.pgm").encode(), big.ctypes.data, big.size, C.byref(w), C.byref(h)) == 0
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        pgm = os.path.join(td, "t.pgm")
+        with open(pgm, "wb") as f:
+            f.write(b"P5\n4 2\n255\n" + bytes(range(8)))
+        assert L.siftgpu_debug_load_image(pgm.encode(), big.ctypes.data, big.size, C.byref(w), C.byref(h)) == 1
+        assert (w.value, h.value) == (4, 2) and list(big[:8]) == list(range(8))

@@ -175,6 +175,28 @@ def test_unreadable_files_return_zero(tmp_path):
     bad = tmp_path / "broken.png"
     bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"not a png at all")
     assert s.run_file(str(bad)) == 0 and s.L.siftgpu_feature_num(s.h) == 0
-    assert s.run_file(os.path.join(fixtures._DATA, "640-1.jpg")) == 0      # JPEG: not decoded by this build
+    bad_jpg = tmp_path / "broken.jpg"
+    bad_jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"not a jpeg at all" * 10)
+    assert s.run_file(str(bad_jpg)) == 0 and s.L.siftgpu_feature_num(s.h) == 0    # libjpeg's error_exit comes back as 0
     assert s.run_file(str(tmp_path / "missing.pgm")) == 0
+    s.close()
+
+
+def test_jpeg_files_are_read_through_libjpeg_at_run_time():
+    """RunSIFT(path) on the reference's own JPEG inputs (data/640-1.jpg; the reference decodes them with DevIL,
+    GLTexImage.cpp:1117-1158): decoded by libjpeg looked up at run time.  Decoders differ in their chroma up-sampling (this
+    image's libjpeg is IJG 9, the tests' PIL carries libjpeg-turbo: 0.5 grey levels apart on average), so the features are
+    compared with the oracle's on PIL-decoded pixels by count and position, not bit for bit."""
+    s = siftgpu_lib.SiftGPU([])
+    assert s.run_file(os.path.join(fixtures._DATA, "640-1.jpg")) == 1
+    k, d = s.features()
+    o = OracleSession(threads=16, keep_levels=False)
+    o.run(fixtures.load_rgb("640-1.jpg")[None])
+    ok, od = o.fetch(0)
+    assert len(ok) > 1000 and abs(len(k) - len(ok)) <= 0.03 * len(ok)
+    # most of the oracle's keypoints have a detected twin within a pixel
+    import scipy.spatial
+    tree = scipy.spatial.cKDTree(np.stack([k["x"], k["y"]], axis=1))
+    dist, _ = tree.query(np.stack([ok["x"], ok["y"]], axis=1))
+    assert np.mean(dist < 1.0) > 0.9
     s.close()
