@@ -171,6 +171,10 @@ struct GaussJob {
   size_t zero_bytes = 0;
 };
 void launch_gauss_job(hipStream_t st, const GaussJob& j, int batch);
+// Levels 0 and 1 of octave 0 from u8 pixels in one launch (level 0 stays in LDS; dst0: stored as well); false: tap counts
+// not instantiated.
+bool launch_gauss_first(hipStream_t st, const uint8_t* pixels, long long pitch, long long img_stride, const Taps& taps0,
+                        const GaussJob& level1, float* dst0, int batch);
 // Two independent level launches in one grid (the top level of an octave and level 1 of the next); false if the pair of
 // tap counts is not instantiated: launch them separately then.
 bool launch_gauss_pair(hipStream_t st, const GaussJob& a, const GaussJob& b, int batch);

@@ -204,6 +204,7 @@ struct hess_ctx {
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
+  bool no_first_fusion = false;    // HESS_NO_FIRST_FUSION: level 0 of octave 0 from a launch of its own, written to HBM (A/B switch)
   bool early_scan = false;         // HESS_EARLY_SCAN: octave 0's extrema scan right behind octave 0's last pyramid launch (A/B switch)
   bool no_top_fusion = false;      // HESS_NO_TOP_FUSION: the top level is stored and its det-H made by a launch of its own (A/B switch)
   bool keep_levels = false;        // hess_debug_keep_levels: the top Gaussian level of every octave is written to HBM as well
@@ -838,7 +839,17 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       top_bytes += level_bytes(o, s.level_max);
       continue;
     }
-    if (o == 0) {
+    bool first_fused = false;  // levels 0 and 1 of octave 0 came out of one launch (level 0 never written)
+    if (o == 0 && direct_u8 && c->has_taps0 && !c->no_first_fusion && s.level_max >= 2 && s.level_ds != 1 && chain_from != 0) {
+      // u8 pixels -> level 0 (LDS) -> level 1, det-H of level 0: the level-0 plane is nobody's input but level 1's
+      const GaussJob j1 = level_job(0, 1);
+      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (1.0 + 4.0 + 4.0), HESS_K_GAUSS_OCT0);
+      first_fused = launch_gauss_first(st, (const uint8_t*)dev, pitch, (long long)image_stride, c->taps0, j1,
+                                       c->keep_levels ? plane_ptr(gauss, 0, 0) : nullptr, batch);
+    }
+    if (o == 0 && first_fused) {
+      // (nothing: level 1 exists, the loop below starts at level 2)
+    } else if (o == 0) {
       if (c->has_taps0) {
         ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (direct_u8 ? 5.0 : 8.0), HESS_K_GAUSS_OCT0);
         if (direct_u8)
@@ -854,7 +865,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       launch_downsample(st, plane_ptr(gauss, o - 1, s.level_ds), g.o[o - 1].wa, g.o[o - 1].plane,
                         plane_ptr(gauss, o, 0), og.wa, og.h, batch);
     }
-    for (int l = 1; l <= s.level_max; l++) {
+    for (int l = first_fused ? 2 : 1; l <= s.level_max; l++) {
       if (l == 1 && deferred_o >= 0) {  // the previous octave's top level rides with this octave's level 1
         const int top_o = deferred_o;
         {
@@ -1660,6 +1671,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
   c->no_top_fusion = getenv("HESS_NO_TOP_FUSION") != nullptr;
   c->early_scan = getenv("HESS_EARLY_SCAN") != nullptr;
+  c->no_first_fusion = getenv("HESS_NO_FIRST_FUSION") != nullptr;
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
@@ -2038,8 +2050,9 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
     return HESS_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   const OctGeom& og = c->g.o[octave];
-  if (what == HESS_DBG_GAUSS && level == c->sch.level_max && !c->keep_levels && !c->no_top_fusion) {
-    set_err(c, "the top Gaussian level is not materialised: call hess_debug_keep_levels before the run");
+  if (what == HESS_DBG_GAUSS && !c->keep_levels &&
+      ((level == c->sch.level_max && !c->no_top_fusion) || (level == 0 && octave == 0 && !c->no_first_fusion))) {
+    set_err(c, "this Gaussian level is not materialised (the octave's top level; level 0 of octave 0): call hess_debug_keep_levels before the run");
     return HESS_ERR_STATE;
   }
   if (what == HESS_DBG_GAUSS || what == HESS_DBG_DETH) {

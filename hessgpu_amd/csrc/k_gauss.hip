@@ -57,16 +57,26 @@ struct GaussArgs {
   long long zero_n16;
   Taps taps;
 };
+// FIRST tiles (octave 0, u8 pixels): `taps0` produces level 0 from the pixels, GaussArgs::taps level 1 from level 0; level 0
+// lives in LDS only (dst0: written as well on request), det-H of level 0 goes to deth_src as for any source level
+struct FirstArgs {
+  Taps taps0;
+  float* dst0;
+};
 
 __device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
 
 // LDS floats of one tile: (32 + 2R) staged rows of 64 + 2*R4 (+4 pad) columns; a TOP tile stages one more row above
 // and below and a column halo of R + 1 (its output tile has a one-pixel halo), and keeps the wrap-around columns of
 // the produced level behind the staged rows (2 x (34 + 2R) horizontally filtered values, 2 x 34 results)
-template <int R, bool TOP = false>
+// A FIRST tile (R0 > 0: level 0 from u8 pixels in LDS, then level 1 from it) has the pixel window instead -- (32 + 2R + 2R0)
+// rows of 64 + 2 (R4 + R0 rounded up to 4) (+4) columns, inside which the level-0 window takes shape in place -- and the wrap
+// columns of level 0.
+template <int R, bool TOP = false, int R0 = 0>
 constexpr int gauss_tile_lds() {
   return TOP ? (TH + 2 * R + 2) * (TW + 2 * ((R + 1 + 3) & ~3) + 4) + ((2 * (TH + 2 + 2 * R) + 2 * (TH + 2) + 3) & ~3)
-             : (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4);
+             : (R0 > 0 ? (TH + 2 * R + 2 * R0) * (TW + 2 * (((R + 3) & ~3) + ((R0 + 3) & ~3)) + 4) + ((2 * (TH + 2 + 2 * R0) + 2 * (TH + 2) + 3) & ~3)
+                       : (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4));
 }
 
 // One 64x32 tile of one level: the body of gauss_kernel, and of either half of gauss_pair_kernel.  `block` = the
@@ -79,8 +89,19 @@ constexpr int gauss_tile_lds() {
 // 1-D index (ProgramCU.cu:523-595): column -1 of a row is the LAST column of the row above, column w the FIRST of the
 // row below -- values of the far side of the image, which tiles at the left / right image border recompute for their
 // 34 rows with the same tap chains (a one-column horizontal + vertical pass from HBM: `wrap` below).
-template <int R, bool U8, bool HESS, bool TOP = false>
-__device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict__ s, const int block, const int nblocks = 0) {
+//
+// FIRST (R0 > 0; octave 0 of a u8 image): level 0 -- nobody's input but level 1's -- is produced from the pixels INSIDE this
+// launch, on the tile grown by level 1's radius, and never written to HBM (a.dst0 only on request): the launch that made
+// level 0 (4 B written per pixel, read back here) is gone.  Borders exactly as two launches have them: the pixel window is
+// staged with clamped rows and replicated edge columns; level 0 at a window position outside the image is level 0 at the
+// clamped position (what level 1's clamped fetch would read), i.e. the horizontally filtered values of outside columns and
+// the level-0 values of outside rows are copies of the edge ones; det-H of level 0 takes its 1-D wrap columns from a
+// one-column pass over the pixels (as TOP tiles do for theirs).
+template <int R, bool U8, bool HESS, bool TOP = false, int R0 = 0>
+__device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict__ s, const int block, const int nblocks = 0,
+                                           const FirstArgs* fa = nullptr) {
+  constexpr bool FIRST = R0 > 0;
+  static_assert(!FIRST || (U8 && HESS && !TOP), "a FIRST tile: u8 pixels in, level 1 + det-H of level 0 out");
   constexpr int FW = 2 * R + 1;
   constexpr int RTOP = TOP ? 1 : 0;    // halo of the output tile
   constexpr int R4 = (R + RTOP + 3) & ~3;
@@ -91,7 +112,16 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
   constexpr int NG = SW / 4;           // 16-byte groups per staged row
   constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
   constexpr int NWH = TH + 2 + 2 * R;  // TOP: horizontally filtered values per wrap column
-  static_assert(ROWS * SWP + (TOP ? ((2 * NWH + 2 * (TH + 2) + 3) & ~3) : 0) == gauss_tile_lds<R, TOP>(), "LDS size");
+  // FIRST: the pixel window A behind the level-0 window s
+  constexpr int R0P = (R0 + 3) & ~3;           // column halo of level 0's horizontal pass, in whole 16-byte groups
+  constexpr int AROWS = ROWS + 2 * R0, ASW = SW + 2 * R0P, ASWP = ASW + 4, ANG = ASW / 4;
+  constexpr int NWH0 = TH + 2 + 2 * R0;
+  static_assert((FIRST ? AROWS * ASWP + ((2 * NWH0 + 2 * (TH + 2) + 3) & ~3)
+                       : ROWS * SWP + (TOP ? ((2 * NWH + 2 * (TH + 2) + 3) & ~3) : 0)) == gauss_tile_lds<R, TOP, R0>(), "LDS size");
+  // The window of the SOURCE level the passes below work on: row stride LSWP, first column at ws.  FIRST: the level-0 window
+  // is computed in place inside the pixel window (its rows are the pixel rows, its columns start R0P in; stride = 4 mod 8 too).
+  constexpr int LSWP = FIRST ? ASWP : SWP;
+  float* const ws = FIRST ? s + R0P : s;
   static_assert(TW - 8 + 4 * NV <= SW, "register windows of the horizontal pass stay inside the staged row");
   static_assert(!TOP || (!U8 && HESS), "a top level has a float source with fused planes");
 
@@ -114,6 +144,182 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
   const int x0 = txi * TW, y0 = tyi * TH;
   const long long img = tz;
 
+  float* const wrap0H = s + AROWS * ASWP;  // FIRST: [2][NWH0] horizontally filtered pixels of the wrap columns
+  float* const wrap0V = wrap0H + 2 * NWH0;               //        [2][TH + 2] level 0 at column w-1 (rows y0-2 ..) / column 0 (rows y0 ..)
+  if (FIRST) {
+    float* const A = s;
+    // ---- stage 0a: pixels -> A: rows y0-R-R0 .. (clamped), columns x0-R4-R0P .. (edge columns replicated) ----
+    {
+      constexpr int ANIT = (AROWS * ANG + NT - 1) / NT;
+      float4 st0[ANIT];
+#pragma unroll
+      for (int it = 0; it < ANIT; it++) {
+        int g = it * NT + tid;
+        g = g < AROWS * ANG ? g : AROWS * ANG - 1;
+        const int r = g / ANG, gq = g - r * ANG;
+        int y = y0 - R - R0 + r;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        const int x = x0 - R4 - R0P + gq * 4;
+        const int xs = x < 0 ? 0 : (x >= w ? w - 4 : x);
+        const uint8_t* row = a.src_u8 + img * a.src_img_stride + (long long)y * a.src_pitch;
+        const uchar4 b = *reinterpret_cast<const uchar4*>(row + xs);
+        st0[it] = make_float4(dm_u8_unit((float)b.x), dm_u8_unit((float)b.y), dm_u8_unit((float)b.z), dm_u8_unit((float)b.w));
+      }
+#pragma unroll
+      for (int it = 0; it < ANIT; it++) {
+        int g = it * NT + tid;
+        g = g < AROWS * ANG ? g : AROWS * ANG - 1;
+        const int r = g / ANG, gq = g - r * ANG;
+        *reinterpret_cast<float4*>(&A[r * ASWP + gq * 4]) = st0[it];
+      }
+      if (x0 - R4 - R0P < 0 || x0 + TW + R4 + R0P > w) {  // block-uniform
+        __syncthreads();
+        for (int g = tid; g < AROWS * ANG; g += NT) {
+          const int r = g / ANG, gq = g - r * ANG;
+          const int x = x0 - R4 - R0P + gq * 4;
+          if (x < 0 || x >= w) {
+            const float e = A[r * ASWP + gq * 4 + (x < 0 ? 0 : 3)];
+            *reinterpret_cast<float4*>(&A[r * ASWP + gq * 4]) = make_float4(e, e, e, e);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- level 0 at the far side of the image for det-H's 1-D neighbour addressing (tiles at the left / right border):
+    // one column, from the pixels, with level 0's own chains ----
+    const bool w0_left = x0 == 0, w0_right = x0 + TW >= w;  // block-uniform
+    if (w0_left || w0_right) {
+      const int side = tid >> 7, t = tid & 127;
+      const bool mine = side == 0 ? w0_left : w0_right;
+      static_assert(NWH0 <= 128, "one thread per filtered row and side");
+      if (mine && t < NWH0) {
+        int yy = (side == 0 ? y0 - 2 : y0) - R0 + t;
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+        const int c = side == 0 ? w - 1 : 0;
+        const uint8_t* row = a.src_u8 + img * a.src_img_stride + (long long)yy * a.src_pitch;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * R0 + 1; i++) {
+          int xx = c - R0 + i;
+          xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+          v = fmaf(dm_u8_unit((float)row[xx]), fa->taps0.k[i], v);
+        }
+        wrap0H[side * NWH0 + t] = v;
+      }
+      __syncthreads();
+      if (mine && t < TH + 2) {
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * R0 + 1; i++) v = fmaf(wrap0H[side * NWH0 + t + i], fa->taps0.k[i], v);
+        wrap0V[side * (TH + 2) + t] = v;
+      }
+    }
+    // ---- stage 0b: horizontal pass of level 0, in place: window columns (A columns R0P .. R0P+SW) <- taps0 ----
+    {
+      constexpr int FW0 = 2 * R0 + 1, OFF0 = R0P - R0, NV0 = (OFF0 + 8 + 2 * R0 + 3) / 4, TPR = SW / 8;
+      constexpr int NT0 = (AROWS * TPR + NT - 1) / NT;
+      static_assert(SW % 8 == 0 && SW - 8 + 4 * NV0 <= ASW, "register windows stay inside the pixel rows");
+      float acc0[NT0][8];
+#pragma unroll
+      for (int k = 0; k < NT0; k++) {
+        const int task = tid + k * NT;
+        if (task < AROWS * TPR) {
+          const int r = task / TPR, xb = (task - r * TPR) * 8;
+          float win[NV0 * 4];
+#pragma unroll
+          for (int i = 0; i < NV0; i++) {
+            const float4 q = *reinterpret_cast<const float4*>(&A[r * ASWP + xb + 4 * i]);
+            win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc0[k][j] = 0.0f;
+#pragma unroll
+          for (int i = 0; i < FW0; i++) {
+            const float ki = fa->taps0.k[i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc0[k][j] = fmaf(win[OFF0 + j + i], ki, acc0[k][j]);  // ProgramCU.cu:152
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NT0; k++) {
+        const int task = tid + k * NT;
+        if (task < AROWS * TPR) {
+          const int r = task / TPR, xb = (task - r * TPR) * 8;
+          *reinterpret_cast<float4*>(&A[r * ASWP + R0P + xb]) = make_float4(acc0[k][0], acc0[k][1], acc0[k][2], acc0[k][3]);
+          *reinterpret_cast<float4*>(&A[r * ASWP + R0P + xb + 4]) = make_float4(acc0[k][4], acc0[k][5], acc0[k][6], acc0[k][7]);
+        }
+      }
+      __syncthreads();
+      if (x0 - R4 < 0 || x0 + TW + R4 > w) {  // block-uniform: window columns outside the image take the edge column's value
+        const int c_lo = R0P + (0 - (x0 - R4)), c_hi = R0P + (w - 1 - (x0 - R4));  // A columns of image columns 0 and w-1
+        for (int idx = tid; idx < AROWS * SW; idx += NT) {
+          const int r = idx / SW, c = R0P + (idx - r * SW);
+          if (c < c_lo) A[r * ASWP + c] = A[r * ASWP + c_lo];
+          else if (c > c_hi) A[r * ASWP + c] = A[r * ASWP + c_hi];
+        }
+        __syncthreads();
+      }
+    }
+    // ---- stage 0c: vertical pass of level 0, in place (window row r <- pixel-window rows r .. r+2 R0; all columns are read
+    // into registers before the first row is overwritten): the level-0 window, as stage 1 stages it for any other level ----
+    {
+      constexpr int FW0 = 2 * R0 + 1, NRG0 = (ROWS + 3) / 4, NCP0 = SW / 2, NTV0 = NRG0 * NCP0, KV0 = (NTV0 + NT - 1) / NT;
+      float2 out[KV0][4];
+#pragma unroll
+      for (int k = 0; k < KV0; k++) {
+        const int t = tid + k * NT;
+        if (t < NTV0) {
+          const int rg = t / NCP0, c = 2 * (t - rg * NCP0);
+          const int r0 = min(4 * rg, ROWS - 4);  // (the last group is moved up onto the window's end: same values)
+          float2 col[4 + 2 * R0];
+#pragma unroll
+          for (int i = 0; i < 4 + 2 * R0; i++) col[i] = *reinterpret_cast<const float2*>(&ws[(r0 + i) * LSWP + c]);
+#pragma unroll
+          for (int j = 0; j < 4; j++) out[k][j] = make_float2(0.0f, 0.0f);
+#pragma unroll
+          for (int i = 0; i < FW0; i++) {
+            const float ki = fa->taps0.k[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              out[k][j].x = fmaf(col[j + i].x, ki, out[k][j].x);  // ProgramCU.cu:226
+              out[k][j].y = fmaf(col[j + i].y, ki, out[k][j].y);
+            }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < KV0; k++) {
+        const int t = tid + k * NT;
+        if (t < NTV0) {
+          const int rg = t / NCP0, c = 2 * (t - rg * NCP0);
+          const int r0 = min(4 * rg, ROWS - 4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) *reinterpret_cast<float2*>(&ws[(r0 + j) * LSWP + c]) = out[k][j];
+        }
+      }
+      __syncthreads();
+      if (y0 - R < 0 || y0 + TH + R > h) {  // block-uniform: window rows outside the image are copies of the edge rows
+        const int r_lo = 0 - (y0 - R), r_hi = h - 1 - (y0 - R);  // window rows of image rows 0 and h-1
+        for (int idx = tid; idx < ROWS * SW; idx += NT) {
+          const int r = idx / SW, c = idx - r * SW;
+          if (r < r_lo) ws[r * LSWP + c] = ws[r_lo * LSWP + c];
+          else if (r > r_hi) ws[r * LSWP + c] = ws[r_hi * LSWP + c];
+        }
+        __syncthreads();
+      }
+      if (fa->dst0) {  // (block-uniform pointer) level 0 itself, only on request
+        float* d0 = fa->dst0 + img * (long long)w * h;
+        for (int idx = tid; idx < TH * (TW / 4); idx += NT) {
+          const int ty = idx / (TW / 4), tx = (idx - ty * (TW / 4)) * 4;
+          if (y0 + ty < h && x0 + tx < w)
+            *reinterpret_cast<float4*>(&d0[(long long)(y0 + ty) * w + x0 + tx]) = *reinterpret_cast<const float4*>(&ws[(R + ty) * LSWP + R4 + tx]);
+        }
+      }
+    }
+  } else {
   // ---- stage 1: global -> LDS, replicate borders (ProgramCU.cu:138, :201) ----
   // All of a thread's loads are issued before its first LDS store, so their HBM latencies overlap.
   constexpr int NIT = (ROWS * NG + NT - 1) / NT;
@@ -159,6 +365,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     }
   }
   __syncthreads();
+  }
 
   // ---- TOP, tiles at the left / right image border: the produced level at the far side of the image, for the 1-D
   // neighbour addressing of det-H.  side 0 (left tiles): column w-1, rows y0-2 .. y0+31 (pixel (0, y) reads rows y-2,
@@ -213,14 +420,14 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       if (gy < h && gx < w) {
         float U[6], M[6], D[6];  // columns gx-1 .. gx+4 of rows gy-1, gy, gy+1
         {
-          const float* base = &s[(hr + R + RTOP - 1) * SWP + hx + R4];
+          const float* base = &ws[(hr + R + RTOP - 1) * LSWP + hx + R4];
 #pragma unroll
           for (int rr = 0; rr < 3; rr++) {
             float* dst = rr == 0 ? U : (rr == 1 ? M : D);
-            const float4 v = *reinterpret_cast<const float4*>(base + rr * SWP);
-            dst[0] = base[rr * SWP - 1];
+            const float4 v = *reinterpret_cast<const float4*>(base + rr * LSWP);
+            dst[0] = base[rr * LSWP - 1];
             dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
-            dst[5] = base[rr * SWP + 4];
+            dst[5] = base[rr * LSWP + 4];
           }
         }
         // The staged window replicates the image border; the reference addresses neighbours by 1-D
@@ -234,12 +441,21 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
 #pragma unroll
           for (int j = 0; j < 6; j++) D[j] = 0.0f;
         }
-        if (gx == 0) {
-          U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
-        }
-        if (gx + 4 == w) {  // this thread owns the row's last pixel (w is a multiple of 4)
-          const int il = idx + 3;
-          U[5] = gtex1(plane, n, il - w + 1); M[5] = gtex1(plane, n, il + 1); D[5] = gtex1(plane, n, il + w + 1);
+        if (FIRST) {  // (the source level is not in HBM: its far-side columns were recomputed above)
+          if (gx == 0) {
+            U[0] = gy >= 2 ? wrap0V[hr] : 0.0f; M[0] = gy >= 1 ? wrap0V[hr + 1] : 0.0f; D[0] = wrap0V[hr + 2];
+          }
+          if (gx + 4 == w) {
+            U[5] = wrap0V[TH + 2 + hr]; M[5] = gy + 1 <= h - 1 ? wrap0V[TH + 2 + hr + 1] : 0.0f; D[5] = gy + 2 <= h - 1 ? wrap0V[TH + 2 + hr + 2] : 0.0f;
+          }
+        } else {
+          if (gx == 0) {
+            U[0] = gtex1(plane, n, idx - w - 1); M[0] = gtex1(plane, n, idx - 1); D[0] = gtex1(plane, n, idx + w - 1);
+          }
+          if (gx + 4 == w) {  // this thread owns the row's last pixel (w is a multiple of 4)
+            const int il = idx + 3;
+            U[5] = gtex1(plane, n, il - w + 1); M[5] = gtex1(plane, n, il + 1); D[5] = gtex1(plane, n, il + w + 1);
+          }
         }
         float hv[4];
         float2 gv[4];
@@ -290,7 +506,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
         float win[NV * 4];
 #pragma unroll
         for (int i = 0; i < NV; i++) {
-          float4 q = *reinterpret_cast<const float4*>(&s[r * SWP + xb + 4 * i]);
+          float4 q = *reinterpret_cast<const float4*>(&ws[r * LSWP + xb + 4 * i]);
           win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
         }
 #pragma unroll
@@ -307,7 +523,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     float hacc = 0.0f;
     static_assert(2 * ROWS <= NT, "one halo task per thread");
     if (TOP && tid < 2 * ROWS) {
-      const float* p = &s[(tid >> 1) * SWP + ((tid & 1) ? OFF + TW : OFF - 1)];
+      const float* p = &ws[(tid >> 1) * LSWP + ((tid & 1) ? OFF + TW : OFF - 1)];
 #pragma unroll
       for (int i = 0; i < FW; i++) hacc = fmaf(p[i], a.taps.k[i], hacc);  // ProgramCU.cu:152
     }
@@ -317,11 +533,11 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       const int task = tid + k * NT;
       if (task < ROWS * (TW / 8)) {
         const int r = task >> 3, xb = (task & 7) * 8;
-        *reinterpret_cast<float4*>(&s[r * SWP + xb]) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
-        *reinterpret_cast<float4*>(&s[r * SWP + xb + 4]) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+        *reinterpret_cast<float4*>(&ws[r * LSWP + xb]) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        *reinterpret_cast<float4*>(&ws[r * LSWP + xb + 4]) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
       }
     }
-    if (TOP && tid < 2 * ROWS) s[(tid >> 1) * SWP + TW + (tid & 1)] = hacc;  // columns 64 (left halo), 65 (right halo) of the row
+    if (TOP && tid < 2 * ROWS) ws[(tid >> 1) * LSWP + TW + (tid & 1)] = hacc;  // columns 64 (left halo), 65 (right halo) of the row
   }
   __syncthreads();
 
@@ -331,7 +547,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
     float2 col[4 + 2 * R];
 #pragma unroll
     for (int i = 0; i < 4 + 2 * R; i++)
-      col[i] = *reinterpret_cast<const float2*>(&s[(rg * 4 + i) * SWP + cg * 2]);
+      col[i] = *reinterpret_cast<const float2*>(&ws[(rg * 4 + i) * LSWP + cg * 2]);
     float2 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[j] = make_float2(0.0f, 0.0f);
@@ -484,6 +700,13 @@ template <int R, bool U8, bool HESS>
 __global__ __launch_bounds__(NT) void gauss_kernel(GaussArgs a) {
   __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R>()];
   gauss_tile<R, U8, HESS>(a, s, (int)blockIdx.x);
+}
+
+// Octave 0 of a u8 image: level 0 in LDS only, level 1 + det-H of level 0 out (gauss_tile, FIRST).
+template <int R0, int R>
+__global__ __launch_bounds__(NT) void gauss_first_kernel(GaussArgs a, FirstArgs fa) {
+  __shared__ __attribute__((aligned(16))) float s[gauss_tile_lds<R, false, R0>()];
+  gauss_tile<R, true, true, false, R0>(a, s, (int)blockIdx.x, 0, &fa);
 }
 
 // The octave's top level: det-H of the produced level from the output tile, the level itself not stored (gauss_tile, TOP).
@@ -935,6 +1158,23 @@ bool launch_pair_b(hipStream_t st, const GaussArgs& a, const GaussArgs& b, int r
   }
 }
 }  // namespace
+
+// Octave 0 of u8 pixels: level 0 (taps0, in LDS only unless dst0 is given) and level 1 (the job: its dst, taps, det-H
+// plane of its source = level 0) in one launch.  Instantiated for the reference's default schedule (13 and 11 taps);
+// false: not this pair of tap counts -- launch level 0 and level 1 one after the other.
+bool launch_gauss_first(hipStream_t st, const uint8_t* pixels, long long pitch, long long img_stride, const Taps& taps0,
+                        const GaussJob& level1, float* dst0, int batch) {
+  if ((taps0.fw >> 1) != 6 || (level1.taps.fw >> 1) != 5 || !level1.deth_src || level1.got_src || level1.deth_dst ||
+      level1.decim_dst || (pitch % 4) != 0 || (img_stride % 4) != 0)
+    return false;
+  GaussArgs a = job_args(level1, batch);
+  a.src = nullptr; a.src_u8 = pixels; a.src_pitch = pitch; a.src_img_stride = img_stride;
+  FirstArgs fa;
+  fa.taps0 = taps0; fa.dst0 = dst0;
+  const int ntile = a.tiles_x * a.tiles_y * batch;
+  hipLaunchKernelGGL((gauss_first_kernel<6, 5>), dim3(((ntile + 7) / 8) * 8), dim3(NT), 0, st, a, fa);
+  return true;
+}
 
 // One level launch described by a job (any level; a job with deth_dst is a top level: TOP tiles).
 void launch_gauss_job(hipStream_t st, const GaussJob& j, int batch) {
