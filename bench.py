@@ -249,6 +249,8 @@ def main():
 
     stamps = [] if os.environ.get("HESS_BENCH_STAMPS") == "1" else None   # completion time of every step (diagnostics, stderr)
 
+    host_submit = [0.0, 0]   # (diagnostics) seconds the submitting thread spent inside the submit call, calls
+
     def run_steps(n, submit):
         """n steps, software-pipelined over the contexts; every step is submitted and finished inside."""
         counts = None
@@ -259,7 +261,13 @@ def main():
                 counts = finish(inflight.pop(0))
                 if stamps is not None:
                     stamps.append(time.perf_counter())
-            submit(c)
+            if stamps is not None:
+                t_sub = time.perf_counter()
+                submit(c)
+                host_submit[0] += time.perf_counter() - t_sub
+                host_submit[1] += 1
+            else:
+                submit(c)
             inflight.append(c)
         while inflight:
             counts = finish(inflight.pop(0))
@@ -285,6 +293,7 @@ def main():
     fence()
     if stamps is not None:
         del stamps[:]
+        host_submit[0], host_submit[1] = 0.0, 0
     t0 = time.perf_counter()
     counts = run_steps(args.steps, submit_resident)
     fence()
@@ -292,6 +301,8 @@ def main():
     if stamps is not None:
         gaps = [stamps[0] - t0] + [b - a for a, b in zip(stamps, stamps[1:])]
         print("bench.py: completion gaps of the timed steps (ms):", " ".join(f"{g * 1e3:.2f}" for g in gaps), file=sys.stderr)
+        print(f"bench.py: the submitting thread spent {host_submit[0] / max(host_submit[1], 1) * 1e3:.3f} ms per step inside the submit call "
+              f"({host_submit[1]} calls; {dt / args.steps * 1e3:.3f} ms per step in all)", file=sys.stderr)
         stamps = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -4,7 +4,7 @@
 # orders as defaults are covered by tests/test_descriptor_order.py), the randomised parity sweep, the determinism soak.
 OUT=gpurun_out/r05_robust; mkdir -p $OUT
 T="tests/test_gpu_parity.py tests/test_reference_inputs_gpu.py tests/test_keypoint_list_gpu.py tests/test_descriptor_order.py tests/test_shared_results.py"
-for v in "HESS_DELIVERY=mirror" "HESS_DELIVERY=blit" "HESS_DELIVERY=dma" "HESS_CHAIN_FROM=2" "HESS_CHAIN_FROM=99" "HESS_NO_PAIR=1" "HESS_SCATTER_SCAN=1" "HESS_SCATTER_SCAN=0" "HESS_COPIER=hip" "HESS_DESC_XCD=0" "HESS_DESC_XCD=1" "HESS_DESC_XCD=3" "HESS_NO_TOP_FUSION=1" "HESS_EARLY_SCAN=1" "HESS_NO_PRIME_BATCH=1"; do
+for v in "HESS_DELIVERY=mirror" "HESS_DELIVERY=blit" "HESS_DELIVERY=dma" "HESS_CHAIN_FROM=2" "HESS_CHAIN_FROM=99" "HESS_NO_PAIR=1" "HESS_SCATTER_SCAN=1" "HESS_SCATTER_SCAN=0" "HESS_COPIER=hip" "HESS_DESC_XCD=0" "HESS_DESC_XCD=1" "HESS_DESC_XCD=3" "HESS_NO_TOP_FUSION=1" "HESS_NO_FIRST_FUSION=1" "HESS_EARLY_SCAN=1" "HESS_NO_PRIME_BATCH=1"; do
   n=$(echo $v | tr '=' '_')
   env $v timeout -k 10 400 python -m pytest $T -m gpu -x -q > $OUT/$n.log 2>&1; echo "$v: $(tail -1 $OUT/$n.log)"
 done

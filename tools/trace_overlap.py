@@ -8,6 +8,9 @@ time with at least one kernel running, mean number of kernels in flight, and per
 its share of the wall time -- set against a single-stream trace this shows which kernels stretch when they overlap.
 Then the IDLE intervals (no kernel in flight): how they are distributed by length, and which kernel ended before / which
 started after the ones that carry the idle time (round 5: where do the pipelined device's gaps come from?).
+Then the hardware queues: per queue the streams it serves, its share of the wall time with a kernel running, and the gaps
+between its consecutive kernels by length; and the time with exactly ONE kernel in flight by that kernel's name (is a
+memory-bound kernel alone on the device while an issue-bound one waits in another queue?).
 """
 import collections
 import csv
@@ -73,6 +76,46 @@ def main():
     print("idle time by (kernel that ended before, kernel that started after, queue): total ms, intervals, mean us")
     for k, (tot, c, _) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:14]:
         print(f"  {tot/1e6:7.3f} ms {c:5d} x {tot/c/1e3:6.1f} us   {k[0]} -> {k[1]} ({k[2]})")
+    # hardware queues
+    byq = collections.defaultdict(list)
+    for r in rows:
+        byq[r[3]].append(r)
+    print("queue: streams, dispatches, busy/wall, gaps between consecutive kernels of the queue (count / ms): <3us, 3-8, 8-20, 20-100, >100")
+    for q, rs in sorted(byq.items()):
+        rs.sort()
+        qbusy = 0; cur_end = rs[0][0]
+        gl = [[0, 0] for _ in range(5)]
+        for a in rs:
+            if a[0] > cur_end:
+                g = a[0] - cur_end
+                i = 0 if g < 3e3 else 1 if g < 8e3 else 2 if g < 20e3 else 3 if g < 100e3 else 4
+                gl[i][0] += 1; gl[i][1] += g
+            qbusy += max(0, a[1] - max(a[0], cur_end))
+            cur_end = max(cur_end, a[1])
+        streams = sorted({a[4] for a in rs})
+        print(f"  queue {q}: streams {','.join(streams)}  {len(rs)} dispatches  busy {qbusy/wall:.3f}  " + "  ".join(f"{c}/{t/1e6:.2f}" for c, t in gl))
+    # time with exactly one kernel in flight, by kernel
+    ev2 = []
+    for i, (s_, e_, *_rest) in enumerate(rows):
+        ev2.append((s_, 1, i)); ev2.append((e_, -1, i))
+    ev2.sort()
+    live = set(); last = t0
+    alone = collections.Counter(); pairs = collections.Counter()
+    for t, k, i in ev2:
+        if len(live) == 1:
+            alone[rows[next(iter(live))][2]] += t - last
+        elif len(live) == 2:
+            a, b = sorted(rows[j][2] for j in live)
+            pairs[(a, b)] += t - last
+        if k > 0: live.add(i)
+        else: live.discard(i)
+        last = t
+    print("time with exactly one kernel in flight, by kernel (share of the wall time):")
+    for n, t in alone.most_common(10):
+        print(f"  {t/wall:.3f}  {n}")
+    print("time with exactly two kernels in flight, by pair:")
+    for (a, b), t in pairs.most_common(14):
+        print(f"  {t/wall:.3f}  {a} + {b}")
 
 
 if __name__ == "__main__":
