@@ -192,6 +192,7 @@ struct hess_ctx {
   }* share_dir = nullptr;
   bool share_by_need = false;      // the shared result buffers are sized by the batches seen, not for the worst case
   DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
+  double stamp_submit0 = 0.0, stamp_submit1 = 0.0;  // HESS_CHAIN_STAMPS
   size_t last_input_bytes = 0;     // bytes of the last batch handed over by hess_submit_host (still in `stage`)
   hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
   // results written by the descriptor kernel straight into the pinned host buffers (no D2H pass after it)
@@ -1799,6 +1800,36 @@ static int check_run_args(hess_ctx* c, const void* pixels, int width, int height
   return 0;
 }
 
+// HESS_CHAIN_STAMPS=1 (diagnostics, stderr): per finished batch the device interval of its launch chain (first event to
+// last event of the context's stream) and the host times of submit / wait return, all in ms since one base that is taken
+// on both clocks when the first batch is submitted -- where do the contexts of a pipelined loop spend their time?
+namespace {
+struct ChainStamps {
+  bool on = getenv("HESS_CHAIN_STAMPS") && atoi(getenv("HESS_CHAIN_STAMPS")) != 0;
+  std::mutex mu;
+  hipEvent_t base = nullptr;
+  std::chrono::steady_clock::time_point host0;
+  double now() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count(); }
+} g_stamps;
+void chain_stamp_submit(hess_ctx* c, bool before) {
+  if (!g_stamps.on) return;
+  std::lock_guard<std::mutex> lk(g_stamps.mu);
+  if (!g_stamps.base) {
+    if (hipEventCreate(&g_stamps.base) != hipSuccess || hipEventRecord(g_stamps.base, c->st) != hipSuccess ||
+        hipEventSynchronize(g_stamps.base) != hipSuccess) { g_stamps.on = false; return; }
+    g_stamps.host0 = std::chrono::steady_clock::now();
+  }
+  (before ? c->stamp_submit0 : c->stamp_submit1) = g_stamps.now();
+}
+void chain_stamp_done(hess_ctx* c, double wait0) {
+  if (!g_stamps.on || !g_stamps.base) return;
+  float a = 0.0f, b = 0.0f;
+  if (hipEventElapsedTime(&a, g_stamps.base, c->ev[0]) != hipSuccess || hipEventElapsedTime(&b, g_stamps.base, c->ev[7]) != hipSuccess) return;
+  fprintf(stderr, "hess chain ctx %p: host submit %.3f - %.3f  device %.3f - %.3f  host wait %.3f - %.3f\n", (void*)c,
+          c->stamp_submit0, c->stamp_submit1, (double)a, (double)b, wait0, g_stamps.now());
+}
+}  // namespace
+
 int hess_submit_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
                        int batch, int format, int pixtype) {
   int rc = check_run_args(c, dev_pixels, width, height, pitch, batch, format, pixtype);
@@ -1808,7 +1839,9 @@ int hess_submit_device(hess_ctx* c, const void* dev_pixels, int width, int heigh
   c->batch = c->pyramid_batch = 0;  // the results and the pyramid of the run before are gone from here on
   if (!c->pend && !(c->pend = new (std::nothrow) PendingRun())) { set_err(c, "out of memory"); return HESS_ERR_NOMEM; }
   *c->pend = PendingRun{dev_pixels, width, height, pitch, batch, format, pixtype, image_stride, 0.0, false, false};
+  chain_stamp_submit(c, true);
   rc = submit_impl(c, *c->pend);
+  chain_stamp_submit(c, false);
   if (rc) return rc;
   c->pend->active = true;
   return 0;
@@ -1819,7 +1852,10 @@ int hess_wait(hess_ctx* c) {
   if (!c->pend || !c->pend->active) { set_err(c, "nothing submitted"); return HESS_ERR_STATE; }
   HIP_TRY(c, hipSetDevice(c->device));
   c->pend->active = false;
-  return wait_impl(c, *c->pend);
+  const double wait0 = g_stamps.on && g_stamps.base ? g_stamps.now() : 0.0;
+  const int rc = wait_impl(c, *c->pend);
+  if (!rc) chain_stamp_done(c, wait0);
+  return rc;
 }
 
 int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
