@@ -193,6 +193,7 @@ struct hess_ctx {
   bool share_by_need = false;      // the shared result buffers are sized by the batches seen, not for the worst case
   DevBuf h_stage;                  // pinned staging of pageable input pixels (hess_submit_host)
   double stamp_submit0 = 0.0, stamp_submit1 = 0.0;  // HESS_CHAIN_STAMPS
+  bool level0_in_lds = false;      // the last run's level 0 of octave 0 was not written to HBM (FIRST tiles)
   size_t last_input_bytes = 0;     // bytes of the last batch handed over by hess_submit_host (still in `stage`)
   hipEvent_t ev_load[2];           // around the host->device transfer of the pixels
   // results written by the descriptor kernel straight into the pinned host buffers (no D2H pass after it)
@@ -848,6 +849,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       first_fused = launch_gauss_first(st, (const uint8_t*)dev, pitch, (long long)image_stride, c->taps0, j1,
                                        c->keep_levels ? plane_ptr(gauss, 0, 0) : nullptr, batch);
     }
+    if (o == 0) c->level0_in_lds = first_fused && !c->keep_levels;
     if (o == 0 && first_fused) {
       // (nothing: level 1 exists, the loop below starts at level 2)
     } else if (o == 0) {
@@ -2087,7 +2089,7 @@ int hess_debug_level(hess_ctx* c, int img, int octave, int level, int what, floa
   HIP_TRY(c, hipSetDevice(c->device));
   const OctGeom& og = c->g.o[octave];
   if (what == HESS_DBG_GAUSS && !c->keep_levels &&
-      ((level == c->sch.level_max && !c->no_top_fusion) || (level == 0 && octave == 0 && !c->no_first_fusion))) {
+      ((level == c->sch.level_max && !c->no_top_fusion) || (level == 0 && octave == 0 && c->level0_in_lds))) {
     set_err(c, "this Gaussian level is not materialised (the octave's top level; level 0 of octave 0): call hess_debug_keep_levels before the run");
     return HESS_ERR_STATE;
   }

@@ -193,7 +193,7 @@ def test_jpeg_files_are_read_through_libjpeg_at_run_time():
     o = OracleSession(threads=16, keep_levels=False)
     o.run(fixtures.load_rgb("640-1.jpg")[None])
     ok, od = o.fetch(0)
-    assert len(ok) > 1000 and abs(len(k) - len(ok)) <= 0.03 * len(ok)
+    assert len(ok) > 150 and abs(len(k) - len(ok)) <= 0.03 * len(ok)
     # most of the oracle's keypoints have a detected twin within a pixel
     import scipy.spatial
     tree = scipy.spatial.cKDTree(np.stack([k["x"], k["y"]], axis=1))

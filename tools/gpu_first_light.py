@@ -18,6 +18,7 @@ def main():
         img = fixtures.load_rgb(name)
     g = hessgpu_amd.HessContext(0, verbose=1, **kw)
     o = OracleSession(threads=8, **kw)
+    g.keep_levels()
     t = time.time(); ng = g.run(img[None]); print("gpu run", ng, "%.1f ms" % ((time.time() - t) * 1e3), flush=True)
     t = time.time(); ng = g.run(img[None]); print("gpu run2", ng, "%.1f ms" % ((time.time() - t) * 1e3), g.timing().round(3), flush=True)
     no = o.run(img[None]); print("oracle", no, flush=True)
