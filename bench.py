@@ -441,6 +441,16 @@ def main():
             if len(ranked) > 1:
                 out["roofline_secondary"] = ranked[1]
             out["kernel_ms_per_step"] = {k: round(v["ms"] / roof_steps, 4) for k, v in prof.items() if v["launches"] and k != "gauss_octave0"}
+            # The whole path over the TIMED (pipelined) step, SURVEY 8(d): A_px = 139.7 B per u8 input pixel (every array of
+            # the reference's layout written once and read once, octaves summed as 4/3) + the per-feature bytes of the
+            # descriptor entry (footprint samples, record, keypoint + descriptor out).
+            dsc = [r for r in roofs if "descriptor" in r["kernel"]]
+            per_step = 139.7 * B * W * H + (dsc[0]["algorithmic_bytes_per_launch"] * dsc[0]["launches_per_step"] if dsc else 0.0)
+            ach = per_step / (dt / args.steps) / 1e9
+            out["roofline_whole_path"] = {
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_step": round(per_step, 1), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "definition": "SURVEY 8(d): 139.7 B per input pixel + per-feature bytes, over ms_per_step of the timed region"}
             # the dominant kernel of the committed kernel trace (top row of the rocprofv3 statistics of the last profiled
             # round), priced with the bytes of that profiled run: a copy, so that the line and the trace name the same kernel
             top = _profile_json("kernel_stats_top.json")
@@ -637,19 +647,28 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False, or
     out = []
     g = prof["gauss"]
     if g["launches"]:
-        achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+        # Algorithmic bytes = SURVEY 8(d)'s accounting: every array of the reference's layout written once and read once
+        # (Gaussian level 4 W + 4 R, det-H 4 W, gradient/theta 8 W per level pixel; 1 B per input pixel).  Two of those
+        # arrays never leave LDS in this build (the octave's top level, level 0 of octave 0: 8 B per pixel each); the bytes
+        # its launches actually have to move are reported beside it (`bytes_moved_per_launch`, what `traffic` compares with).
+        layout = g["bytes"] + g.get("bytes_in_lds", 0.0)
+        achieved = layout / (g["ms"] * 1e-3) / 1e9
+        moved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         out.append({
             "bound": "hbm",
-            "kernel": "gauss_kernel / gauss_pair_kernel (separable Gaussian + fused det-Hessian/gradient; one pyramid level of the batch per launch, the top level of an octave shares its launch with level 1 of the next)",
+            "kernel": "gauss_kernel / gauss_pair_kernel / gauss_first_kernel (separable Gaussian + fused det-Hessian/gradient; one pyramid level of the batch per launch; levels 0 + 1 of octave 0 share a launch, the top level of an octave shares one with level 1 of the next)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profile_value("gauss_traffic.json", "hbm_bytes_per_launch"),
             "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
-            "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"], 1),
+            "algorithmic_bytes_per_launch": round(layout / g["launches"], 1),
+            "algorithmic_bytes": "SURVEY 8(d): the reference's arrays, each written once and read once, for the levels these launches produce",
+            "bytes_moved_per_launch": round(g["bytes"] / g["launches"], 1),
+            "achieved_on_bytes_moved": round(moved, 1), "frac_on_bytes_moved": round(moved / HBM_PEAK_GBS, 4),
             "launches": g["launches"], "ms_per_step": round(g["ms"] / steps, 4),
         })
         mix = _profile_value("hbm_mix.json", "one_read_four_writes_gbs")
         if mix:  # what this chip sustains for a level launch's traffic mix (4 B read, 16 B written per pixel)
-            out[-1]["achievable_for_mix"] = {"peak": mix, "unit": "GB/s", "frac": round(achieved / mix, 4),
+            out[-1]["achievable_for_mix"] = {"peak": mix, "unit": "GB/s", "frac": round(moved / mix, 4),
                                              "source": "tools/micro/hbm_mix.hip, one read to four writes (profiles/r03_hbm_mix.txt); "
                                                        "the octave-0 launches alone run at 0.87-0.97 of it, the latency-bound "
                                                        "launches of the smaller octaves pull the stage's average down"}
@@ -657,13 +676,18 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False, or
         if g0 and g0["launches"]:
             # the launches that work on octave 0 (three quarters of the stage's bytes): large enough to be bound by
             # memory bandwidth; the rest of the stage is the dependent chain of small launches of the other octaves
-            a0 = g0["bytes"] / (g0["ms"] * 1e-3) / 1e9
+            layout0 = g0["bytes"] + g0.get("bytes_in_lds", 0.0)
+            a0 = layout0 / (g0["ms"] * 1e-3) / 1e9
+            m0 = g0["bytes"] / (g0["ms"] * 1e-3) / 1e9
             out[-1]["octave0_launches"] = {
                 "launches": g0["launches"], "avg_launch_us": round(g0["ms"] * 1e3 / g0["launches"], 2),
-                "algorithmic_bytes_per_launch": round(g0["bytes"] / g0["launches"], 1),
-                "share_of_stage_bytes": round(g0["bytes"] / g["bytes"], 3), "share_of_stage_time": round(g0["ms"] / g["ms"], 3),
+                "algorithmic_bytes_per_launch": round(layout0 / g0["launches"], 1),
+                "bytes_moved_per_launch": round(g0["bytes"] / g0["launches"], 1),
+                "share_of_stage_bytes": round(layout0 / layout, 3), "share_of_stage_time": round(g0["ms"] / g["ms"], 3),
                 "achieved": round(a0, 1), "unit": "GB/s", "frac": round(a0 / HBM_PEAK_GBS, 4),
-                "frac_of_mix": round(a0 / mix, 4) if mix else None}
+                "achieved_on_bytes_moved": round(m0, 1),
+                # (the mix rate is a rate of bytes that move: compared with the moved bytes)
+                "frac_of_mix": round(m0 / mix, 4) if mix else None}
         gi = _profile_value("gauss_traffic.json", "valu_insts_per_image")
         if gi:
             rate = gi * images * steps / (g["ms"] * 1e-3) / 1e9

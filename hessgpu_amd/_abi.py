@@ -124,6 +124,7 @@ PRODUCT_PROTOTYPES = {
     "profile_enable": (C.c_int, [_ctx, C.c_int]),
     "profile_get": (C.c_int, [_ctx, C.c_int, _P(C.c_double), _P(C.c_longlong), _P(C.c_double)]),
     "profile_reset": (C.c_int, [_ctx]),
+    "profile_get_in_lds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_double)]),
     "debug_regrown": (C.c_int, [_ctx]),
     "debug_keep_levels": (C.c_int, [_ctx, C.c_int]),
     "last_input": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),

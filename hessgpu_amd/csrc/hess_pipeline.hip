@@ -63,6 +63,7 @@ struct EventPair {
   int kernel;
   double bytes;
   int kernel2 = -1;  // a second accumulator for the same launch (HESS_K_GAUSS_OCT0), or -1
+  double in_lds = 0.0;  // bytes of the reference's array layout this launch neither writes nor reads: the array lives in LDS only
 };
 
 }  // namespace
@@ -247,6 +248,7 @@ struct hess_ctx {
   double k_ms[HESS_K_COUNT];
   long long k_n[HESS_K_COUNT];
   double k_bytes[HESS_K_COUNT];
+  double k_in_lds[HESS_K_COUNT];   // hess_profile_get_in_lds
 };
 
 namespace {
@@ -652,9 +654,9 @@ struct ProfScope {
   hess_ctx* c;
   EventPair ep;
   bool on;
-  ProfScope(hess_ctx* ctx, int kernel, double bytes, int kernel2 = -1) : c(ctx), on(ctx->prof) {
+  ProfScope(hess_ctx* ctx, int kernel, double bytes, int kernel2 = -1, double in_lds = 0.0) : c(ctx), on(ctx->prof) {
     if (!on) return;
-    ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes; ep.kernel2 = kernel2;
+    ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = bytes; ep.kernel2 = kernel2; ep.in_lds = in_lds;
     if (!ep.a || !ep.b) {  // event creation failed: no record for this launch
       if (ep.a) c->pool.push_back(ep.a);
       if (ep.b) c->pool.push_back(ep.b);
@@ -676,7 +678,10 @@ void drain_profile(hess_ctx* c) {
       c->k_ms[ep.kernel] += ms;
       c->k_n[ep.kernel] += 1;
       c->k_bytes[ep.kernel] += ep.bytes;
-      if (ep.kernel2 >= 0) { c->k_ms[ep.kernel2] += ms; c->k_n[ep.kernel2] += 1; c->k_bytes[ep.kernel2] += ep.bytes; }
+      c->k_in_lds[ep.kernel] += ep.in_lds;
+      if (ep.kernel2 >= 0) {
+        c->k_ms[ep.kernel2] += ms; c->k_n[ep.kernel2] += 1; c->k_bytes[ep.kernel2] += ep.bytes; c->k_in_lds[ep.kernel2] += ep.in_lds;
+      }
     }
     c->pool.push_back(ep.a);
     c->pool.push_back(ep.b);
@@ -783,6 +788,11 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     const bool decim = fused_decim && l == s.level_ds && o + 1 < g.noct;
     return (double)batch * og.plane * (8.0 + 4.0 + (src_got ? 8.0 : 0.0)) + (decim ? (double)batch * g.o[o + 1].plane * 4.0 : 0.0);
   };
+  // (SURVEY 8d books every array of the reference's layout written once and read once; a level this build keeps in LDS
+  // -- the octave's top level, level 0 of octave 0 -- is 8 bytes per pixel of that layout which no launch here moves)
+  auto level_in_lds = [&](int o, int l) {
+    return (top_fused && l == s.level_max && !c->keep_levels) ? (double)batch * g.o[o].plane * 8.0 : 0.0;
+  };
   auto launch_level = [&](const GaussJob& j) {
     if (j.zero) c->zero_filled = true;
     launch_gauss_job(st, j, batch);
@@ -815,7 +825,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   const bool chained = chain_from < g.noct;
   GaussJob top_jobs[kMaxOct];  // the top levels of the octaves that do not ride with the next octave's level 1
   int ntop = 0;
-  double top_bytes = 0.0;
+  double top_bytes = 0.0, top_in_lds = 0.0;
   int deferred_o = -1;
   for (int o = 0; o < g.noct; o++) {
     const OctGeom& og = g.o[o];
@@ -839,13 +849,15 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       }
       top_jobs[ntop++] = level_job(o, s.level_max);
       top_bytes += level_bytes(o, s.level_max);
+      top_in_lds += level_in_lds(o, s.level_max);
       continue;
     }
     bool first_fused = false;  // levels 0 and 1 of octave 0 came out of one launch (level 0 never written)
     if (o == 0 && direct_u8 && c->has_taps0 && !c->no_first_fusion && s.level_max >= 2 && s.level_ds != 1 && chain_from != 0) {
       // u8 pixels -> level 0 (LDS) -> level 1, det-H of level 0: the level-0 plane is nobody's input but level 1's
       const GaussJob j1 = level_job(0, 1);
-      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (1.0 + 4.0 + 4.0), HESS_K_GAUSS_OCT0);
+      ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (1.0 + 4.0 + 4.0), HESS_K_GAUSS_OCT0,
+                   c->keep_levels ? 0.0 : (double)batch * og.plane * 8.0);
       first_fused = launch_gauss_first(st, (const uint8_t*)dev, pitch, (long long)image_stride, c->taps0, j1,
                                        c->keep_levels ? plane_ptr(gauss, 0, 0) : nullptr, batch);
     }
@@ -873,7 +885,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         const int top_o = deferred_o;
         {
           const GaussJob ja = level_job(top_o, s.level_max), jb = level_job(o, 1);
-          ProfScope ps(c, HESS_K_GAUSS, level_bytes(top_o, s.level_max) + level_bytes(o, 1), top_o == 0 ? HESS_K_GAUSS_OCT0 : -1);
+          ProfScope ps(c, HESS_K_GAUSS, level_bytes(top_o, s.level_max) + level_bytes(o, 1), top_o == 0 ? HESS_K_GAUSS_OCT0 : -1,
+                       level_in_lds(top_o, s.level_max));
           if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
           else { launch_level(ja); launch_level(jb); }
         }
@@ -884,19 +897,20 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       if (l == s.level_max && chained && o + 1 >= chain_from) {  // with the chained octaves' top levels, after the chain
         top_jobs[ntop++] = level_job(o, l);
         top_bytes += level_bytes(o, l);
+        top_in_lds += level_in_lds(o, l);
         continue;
       }
       if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
-      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l), o == 0 ? HESS_K_GAUSS_OCT0 : -1);
+      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l), o == 0 ? HESS_K_GAUSS_OCT0 : -1, level_in_lds(o, l));
       launch_level(level_job(o, l));
     }
   }
   if (deferred_o >= 0) {  // (cannot happen: the last octave never defers)
-    ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max));
+    ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max), -1, level_in_lds(deferred_o, s.level_max));
     launch_level(level_job(deferred_o, s.level_max));
   }
   if (ntop) {  // the top levels left over by the chain, one launch
-    ProfScope ps(c, HESS_K_GAUSS, top_bytes);
+    ProfScope ps(c, HESS_K_GAUSS, top_bytes, -1, top_in_lds);
     // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves, from HBM: hessian_low_levels)
     LowLevels low{&g, gauss, deth, got, s.norm, chain_from, chained ? s.level_ds : 0};
     if (launch_gauss_multi(st, top_jobs, ntop, batch, &low)) {
@@ -1650,6 +1664,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   memset(c->k_ms, 0, sizeof(c->k_ms));
   memset(c->k_n, 0, sizeof(c->k_n));
   memset(c->k_bytes, 0, sizeof(c->k_bytes));
+  memset(c->k_in_lds, 0, sizeof(c->k_in_lds));
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
     fprintf(stderr, "hessgpu: cannot create stream on device %d\n", device);
     delete c;
@@ -2183,6 +2198,7 @@ int hess_profile_reset(hess_ctx* c) {
   memset(c->k_ms, 0, sizeof(c->k_ms));
   memset(c->k_n, 0, sizeof(c->k_n));
   memset(c->k_bytes, 0, sizeof(c->k_bytes));
+  memset(c->k_in_lds, 0, sizeof(c->k_in_lds));
   return 0;
 }
 int hess_profile_get(hess_ctx* c, int kernel, double* ms, long long* launches, double* bytes) {
@@ -2190,6 +2206,12 @@ int hess_profile_get(hess_ctx* c, int kernel, double* ms, long long* launches, d
   if (ms) *ms = c->k_ms[kernel];
   if (launches) *launches = c->k_n[kernel];
   if (bytes) *bytes = c->k_bytes[kernel];
+  return 0;
+}
+
+int hess_profile_get_in_lds(hess_ctx* c, int kernel, double* bytes) {
+  if (!c || !bytes || kernel < 0 || kernel >= HESS_K_COUNT) return HESS_ERR_ARG;
+  *bytes = c->k_in_lds[kernel];
   return 0;
 }
 

@@ -226,4 +226,8 @@ class Session:
             ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
             self._check(self._f["profile_get"](self._h, k, C.byref(ms), C.byref(n), C.byref(by)))
             out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value}
+            if "profile_get_in_lds" in self._f:   # bytes of the reference's layout that never left LDS (hess_abi.h)
+                il = C.c_double()
+                self._check(self._f["profile_get_in_lds"](self._h, k, C.byref(il)))
+                out[name]["bytes_in_lds"] = il.value
         return out

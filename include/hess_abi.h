@@ -273,6 +273,11 @@ int hess_profile_enable(hess_ctx* ctx, int on);
 /* Accumulated since the last hess_profile_reset: total ms, launches, algorithmic bytes. */
 int hess_profile_get(hess_ctx* ctx, int kernel, double* ms, long long* launches, double* bytes);
 int hess_profile_reset(hess_ctx* ctx);
+/* Bytes of the REFERENCE's array layout (every array written once and read once) that the launches counted
+ * under `kernel` neither wrote nor read because the array never left LDS: the octave's top Gaussian level (its det-H
+ * comes out of the launch that produces it) and level 0 of octave 0 of a u8 image -- 8 bytes per pixel each.
+ * hess_profile_get's bytes are what the launches have to move; bytes + this = the layout's figure. */
+int hess_profile_get_in_lds(hess_ctx* ctx, int kernel, double* bytes);
 
 /* ---- Descriptor matcher: replaces SiftMatchGPU's CUDA flavour, SiftMatchCU
  * (SiftMatchCU.cpp:71-176) and MultiplyDescriptor(_G)_Kernel / RowMatch_Kernel / ColMatch_Kernel

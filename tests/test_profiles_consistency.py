@@ -20,8 +20,11 @@ def test_gauss_traffic_is_plausible():
     # a 1080p pyramid with its fused det-H / gradient stage: 1.5e7 - 2.5e7 vector instructions per image
     assert 1.0e7 < t["valu_insts_per_image"] < 3.0e7, t["valu_insts_per_image"]
     assert t["valu_insts_steps_in_pass"] >= 1
-    # HBM traffic per launch within a few per cent of the algorithmic bytes (each level read once, written once)
-    assert 0.95 < t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.15
+    # HBM traffic per launch within a few per cent of the bytes the launches have to move (each level they store read once,
+    # written once); the algorithmic figure (the reference's layout) also counts the two levels kept in LDS
+    moved = t.get("bytes_moved_per_launch", t["algorithmic_bytes_per_launch"])
+    assert 0.95 < t["hbm_bytes_per_launch"] / moved < 1.15
+    assert 1.0 <= t["algorithmic_bytes_per_launch"] / moved < 1.3
     # the nominal issue peak cannot be exceeded by the rate this implies at the committed kernel time (about 0.5 ms per
     # step of eight images): instructions x 8 / 0.5 ms < 1228.8 Ginst/s
     assert t["valu_insts_per_image"] * 8 / 0.5e-3 / 1e9 < 1228.8

@@ -22,7 +22,8 @@ def main():
     rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(d, "counters.csv")))}
     clock = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(d, "clock.csv")))} if os.path.exists(os.path.join(d, "clock.csv")) else {}
     g = bench["roofline"] if bench["roofline"]["kernel"].startswith("gauss") else bench["roofline_secondary"]
-    traffic["algorithmic_bytes_per_launch"] = g["algorithmic_bytes_per_launch"]
+    traffic["algorithmic_bytes_per_launch"] = g["algorithmic_bytes_per_launch"]   # the reference's array layout
+    traffic["bytes_moved_per_launch"] = g.get("bytes_moved_per_launch", g["algorithmic_bytes_per_launch"])   # without the arrays kept in LDS
     traffic["source"] = f"profiles/{tag}_* (tools/profile_round.sh {tag})"
     # vector instructions of all Gaussian launches per image.  The number of steps the SQ pass ran is READ from the pass
     # (every step launches the extrema scan exactly once), never assumed: round 3 divided by a hard-coded 3 after the
@@ -32,7 +33,7 @@ def main():
     steps = sum(int(r["launches"]) for r in scan)
     if steps <= 0:
         raise SystemExit("make_profile_json: no extrema scan launches in counters.csv: cannot tell how many steps the pass ran")
-    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_tail_kernel")))
+    gv = sum(float(r["SQ_INSTS_VALU"]) * int(r["launches"]) for k, r in rows.items() if k.startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_first_kernel", "gauss_tail_kernel")))
     traffic["valu_insts_per_image"] = round(gv / (steps * batch), 1)
     traffic["valu_insts_steps_in_pass"] = steps
     if not (1.0e6 < traffic["valu_insts_per_image"] < 1.0e8):   # a 1080p pyramid is 1.5e7 - 2.5e7 vector instructions
@@ -142,7 +143,7 @@ def kernel_stats_top(d, tag, bench):
                     "achieved": round(b / avg_s / 1e9, 1), "frac": round(b / avg_s / 1e9 / 8000.0, 4),
                     "hipevents_avg_launch_us_same_run": e["avg_launch_us"]})
     else:  # one instantiation of the Gaussian kernel leads the table: price the whole family (all its rows) instead
-        fam = [x for x in rows if short(x["Name"]).startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_tail_kernel"))]
+        fam = [x for x in rows if short(x["Name"]).startswith(("gauss_kernel", "gauss_pair_kernel", "gauss_top_kernel", "gauss_first_kernel", "gauss_tail_kernel"))]
         tot_s = sum(float(x["TotalDurationNs"]) for x in fam) * 1e-9
         calls = sum(int(x["Calls"]) for x in fam)
         per_step = max(1, round(e["ms_per_step"] * 1e3 / e["avg_launch_us"]))  # Gaussian launches per step (bench line)
@@ -152,6 +153,9 @@ def kernel_stats_top(d, tag, bench):
                     "calls": calls, "avg_launch_us": round(tot_s / calls * 1e6, 2), "launches_per_step": per_step,
                     "algorithmic_bytes_per_step": bytes_step, "achieved": round(bytes_step * steps / tot_s / 1e9, 1),
                     "frac": round(bytes_step * steps / tot_s / 1e9 / 8000.0, 4)})
+        if "bytes_moved_per_launch" in e:   # (the layout's bytes above; what the launches move, beside it)
+            moved_step = e["bytes_moved_per_launch"] * per_step
+            out.update({"bytes_moved_per_step": moved_step, "achieved_on_bytes_moved": round(moved_step * steps / tot_s / 1e9, 1)})
     return out
 
 
