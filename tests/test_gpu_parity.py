@@ -472,3 +472,25 @@ def test_repeatability(gpu_ctx_factory):
         g.run(img[None])
         k, d = g.fetch(0)
         assert k.tobytes() == k0.tobytes() and d.tobytes() == d0.tobytes()
+
+
+@pytest.mark.gpu
+def test_profile_bytes_are_the_layouts_of_survey_8d(gpu_ctx_factory):
+    """The roofline numerator of the Gaussian + det-H stage: bytes the launches move (hess_profile_get) + bytes of the arrays
+    kept in LDS (hess_profile_get_in_lds) = SURVEY 8(d)'s layout -- per octave pixel Gaussian 5 levels x (4 W + 4 R), det-H
+    5 x 4 W, gradient/theta 3 x 8 W = 84 B (level 0 of an octave > 0 is written by the octave before), + 1 B per u8 pixel."""
+    B, H, W = 3, 270, 480
+    imgs = np.stack([fixtures.synthetic_blobs(W, H, i) for i in range(B)])
+    g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=500)
+    g.run(imgs)
+    g.profile_enable(True)
+    g.profile_reset()
+    g.run(imgs)
+    p = g.profile()["gauss"]
+    g.profile_enable(False)
+    planes = [w * h for w, h in g.geometry()]
+    layout = B * (sum(84.0 * px for px in planes) + 1.0 * planes[0])
+    assert p["launches"] > 0 and p["bytes_in_lds"] > 0
+    assert abs(p["bytes"] + p["bytes_in_lds"] - layout) < 1e-6 * layout, (p, layout)
+    # what stays in LDS: the top level of every octave and level 0 of octave 0, written once and read once in the layout
+    assert abs(p["bytes_in_lds"] - B * 8.0 * (sum(planes) + planes[0])) < 1e-6 * layout
