@@ -669,9 +669,9 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False, or
         mix = _profile_value("hbm_mix.json", "one_read_four_writes_gbs")
         if mix:  # what this chip sustains for a level launch's traffic mix (4 B read, 16 B written per pixel)
             out[-1]["achievable_for_mix"] = {"peak": mix, "unit": "GB/s", "frac": round(moved / mix, 4),
-                                             "source": "tools/micro/hbm_mix.hip, one read to four writes (profiles/r03_hbm_mix.txt); "
-                                                       "the octave-0 launches alone run at 0.87-0.97 of it, the latency-bound "
-                                                       "launches of the smaller octaves pull the stage's average down"}
+                                             "source": "tools/micro/hbm_mix_layout.hip, one read to four writes into planes that do not share "
+                                                       "HBM channels (profiles/r05_experiments/hbm_mix_layout.txt; round 3's 4 637 GB/s was the "
+                                                       "worst case of planes exactly 512 MiB apart); of the moved bytes"}
         g0 = prof.get("gauss_octave0")
         if g0 and g0["launches"]:
             # the launches that work on octave 0 (three quarters of the stage's bytes): large enough to be bound by
