@@ -596,6 +596,11 @@ def configs4_leg(local_rank, torch):
     dur = dk["ms"] * 1e-3 / max(1, dk["launches"])
     s_oct = keys["s"].astype(np.float64) / (2.0 ** (keys["level"] // 3))
     fbytes = float(np.sum((15.0 * s_oct) ** 2 * 8.0 + 16.0 + 24.0 + 256.0))
+    # (one large image delivered by the copier thread has its descriptors in four launches over quarters of its features)
+    per_image = max(1, round(dk["launches"] / 5))
+    fbytes /= per_image
+    n_launch = int(round(n / per_image))
+    mirror = _mirror_is_default(1, result_bytes=n * (24 + 64 * 4))
     return {
         "workload": "4096x4096 synthetic blobs, -maxd 4096 -topk 65536 -half (64-d descriptors) [configs[4]]",
         "features": n,
@@ -603,9 +608,10 @@ def configs4_leg(local_rank, torch):
         "Mpix_per_s_three_contexts": round(S * S / dt / 1e6, 1), "ms_per_image_three_contexts": round(dt * 1e3, 3),
         "kernel_ms_per_image": {k: round(v["ms"] / 5, 4) for k, v in prof.items() if v["launches"]},
         "roofline_descriptor": {
-            "bound": "hbm", "kernel": _desc_kernel_name(int(ctxs[0].params.descriptor_order), _mirror_is_default(1)) + " (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
+            "bound": "hbm", "kernel": _desc_kernel_name(int(ctxs[0].params.descriptor_order), mirror) + " (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / dur / 1e9 / HBM_PEAK_GBS, 4),
-            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1), "features_per_launch": n,
+            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": round(fbytes, 1), "features_per_launch": n_launch,
+            "launches_per_image": per_image,
         },
     }
 
@@ -623,13 +629,16 @@ def _valu_entry(rate, insts, unit_key, source):
     return e
 
 
-def _mirror_is_default(batch):
+def _mirror_is_default(batch, result_bytes=None):
     """Whether a batch of this size is delivered by the descriptor kernel's own host stores (hess_pipeline.hip,
-    choose_delivery): HESS_DELIVERY overrides, else batches up to HESS_MIRROR_MAX_BATCH (2)."""
+    choose_delivery): HESS_DELIVERY overrides, else batches up to HESS_MIRROR_MAX_BATCH (2) whose results (keypoints +
+    descriptors of the context's batch before) stay within HESS_MIRROR_MAX_MB (16)."""
     pref = os.environ.get("HESS_DELIVERY")
     if pref in ("mirror", "dma", "blit"):
         return pref == "mirror"
-    return batch <= int(os.environ.get("HESS_MIRROR_MAX_BATCH", "2"))
+    if result_bytes is None:
+        result_bytes = batch * 6000 * (24 + 128 * 4)   # the bench workload: about 5.6 k features per image, 128-d
+    return batch <= int(os.environ.get("HESS_MIRROR_MAX_BATCH", "2")) and result_bytes <= (int(os.environ.get("HESS_MIRROR_MAX_MB", "16")) << 20)
 
 
 def _desc_kernel_name(order, mirror):

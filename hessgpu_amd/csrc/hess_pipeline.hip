@@ -110,6 +110,7 @@ struct Copier {
   static constexpr int kMaxParts = 4;
   hipEvent_t ev_part[kMaxParts - 1] = {nullptr, nullptr, nullptr};
   int nparts = 1, part_end[kMaxParts] = {0, 0, 0, 0};
+  bool part_features = false;  // the parts are ranges of ONE image's features (part k ends at feature n (k + 1) / nparts), not groups of images
   // ROCr side (SDMA): agents owning the device / pinned host buffers, engine, completion signal
   bool hsa_ready = false, hsa_failed = false;
   hsa_agent_t gpu_agent{}, cpu_agent{};
@@ -202,6 +203,10 @@ struct hess_ctx {
   bool host_fits = false;          // the pinned result buffers hold the worst case of the current plan
   int delivery = kDeliverMirror;   // of the submitted batch (choose_delivery)
   int nparts = 1, part_end[Copier::kMaxParts] = {0, 0, 0, 0};  // the submitted batch's descriptor launches (groups of images)
+  bool part_features = false;      // ... or, for one large image, ranges of its features (DescParams::part)
+  size_t mirror_max_bytes = (size_t)16 << 20;  // HESS_MIRROR_MAX_MB: result bytes (of the context's last batch) up to which a small batch uses the in-kernel mirror
+  size_t last_result_bytes = 0;    // keypoints + descriptors the last batch delivered, and its size
+  int last_result_batch = 0;
   int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
   int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
@@ -1011,6 +1016,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
   dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   dsp.first_image = 0;
+  dsp.part = 0; dsp.part_den = 1;
   dsp.xcd_block = c->desc_xcd_block;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   // the pixel order's fixed point assumes luminance in [0, 1] (8- and 16-bit inputs); float pixels are taken as they are
@@ -1021,23 +1027,31 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // computed -- half of the transfer (0.53 ms for eight 1080p images) leaves the batch's critical path.  Four groups
   // shorten a lone batch a little more (1.75 / 1.58 / 1.53 ms for 1 / 2 / 4) but cost the pipelined rate 1 %:
   // HESS_DESC_PARTS=n overrides (1: one launch, up to kMaxParts).
+  // ONE image delivered by the copier thread (a large one: choose_delivery) gets its descriptors in four launches over
+  // quarters of its feature list, for the same reason (a 4096^2 image with 102 k half descriptors: 28 MB, 0.58 ms on the
+  // link; 2.09 -> 1.7 ms per image on one context).
   {
     int want = batch >= 4 ? 2 : 1;
-    if (c->desc_parts > 0) want = std::max(1, std::min<int>(Copier::kMaxParts, std::min(batch, c->desc_parts)));
+    c->part_features = false;
+    if (batch == 1 && c->delivery == kDeliverDma) { want = Copier::kMaxParts; c->part_features = true; }
+    if (c->desc_parts > 0) want = std::max(1, std::min<int>(Copier::kMaxParts, c->part_features ? c->desc_parts : std::min(batch, c->desc_parts)));
     if (c->delivery != kDeliverDma || !c->cp.ev_part[0]) want = 1;
+    if (want == 1) c->part_features = false;
     c->nparts = want;
-    for (int k = 0; k < want; k++) c->part_end[k] = (int)((long long)batch * (k + 1) / want);
+    for (int k = 0; k < want; k++) c->part_end[k] = c->part_features ? 1 : (int)((long long)batch * (k + 1) / want);
   }
   {
     int first = 0;
     for (int k = 0; k < c->nparts; k++) {
       ProfScope ps(c, HESS_K_DESCRIPTOR, 0.0);  // (per launch, so that the counts agree with a kernel trace)
       dsp.first_image = first;
+      dsp.part = c->part_features ? k : 0;
+      dsp.part_den = c->part_features ? c->nparts : 1;
       launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                         (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                         (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, c->part_end[k] - first);
       if (k < c->nparts - 1) HIP_TRY(c, hipEventRecord(c->cp.ev_part[k], st));
-      first = c->part_end[k];
+      if (!c->part_features) first = c->part_end[k];
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev[7], st));
@@ -1152,10 +1166,12 @@ int enqueue_user(hess_ctx* c) {
   dsp.hkeys = c->host_direct ? (HostKeypoint*)c->h_keys.p : nullptr;
   dsp.hdesc = (c->host_direct && c->dim) ? (float*)c->h_desc.p : nullptr;
   dsp.first_image = 0;
+  dsp.part = 0; dsp.part_den = 1;
   dsp.xcd_block = c->desc_xcd_block;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   dsp.pixel = 0;  // a keypoint list is described in a floating-point order (interleaved unless the sequential one is asked for)
   c->nparts = 1;
+  c->part_features = false;
   launch_descriptor(st, g, dsp, list, c->cap_raw, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                     (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
                     (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, 1);
@@ -1376,6 +1392,7 @@ void copier_main(hess_ctx* c) {
       PendingRun& r = *cp.run;
       r.t_load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       cp.nparts = 1;
+      cp.part_features = false;
       if (!rc) {
         try {
           rc = enqueue(c, r.dev, r.pitch, r.image_stride, r.batch, r.format, r.pixtype);
@@ -1384,6 +1401,7 @@ void copier_main(hess_ctx* c) {
         if (rc && !msg[0]) snprintf(msg, sizeof(msg), "%s", c->err.c_str());
         if (!rc) {  // (a half-run enqueue leaves no parts to wait for)
           cp.nparts = c->nparts;
+          cp.part_features = c->part_features;
           for (int k = 0; k < Copier::kMaxParts; k++) cp.part_end[k] = c->part_end[k];
         }
       }
@@ -1425,7 +1443,9 @@ void copier_main(hess_ctx* c) {
       size_t done_feats = 0;
       for (int k = 0; k < nparts; k++) {
         if (k > 0 && (e = hipEventSynchronize(k < nparts - 1 ? cp.ev_part[k] : cp.ev_done)) != hipSuccess) fail("hipEventSynchronize", e);
-        const size_t upto = overflow ? 0 : (k < nparts - 1 ? (size_t)hs[cp.part_end[k]] : total);  // features of the images so far
+        // features of the images so far -- or, of one image's list, the bound the part's launch formed (k_feature.hip, feature_part)
+        const size_t upto = overflow ? 0 : (k == nparts - 1 ? total : cp.part_features ? (size_t)((long long)total * (k + 1) / nparts)
+                                                                                     : (size_t)hs[cp.part_end[k]]);
         copy_part(done_feats, upto - done_feats);
         done_feats = upto;
       }
@@ -1480,7 +1500,15 @@ void copier_stop(hess_ctx* c) {
 // descriptor kernel's own stores (lowest latency), larger ones by the copier thread's DMA copy (no kernel waits for
 // PCIe).  HESS_DELIVERY overrides.
 void choose_delivery(hess_ctx* c, int batch) {
-  int d = c->delivery_pref >= 0 ? c->delivery_pref : (batch <= c->mirror_max_batch ? kDeliverMirror : kDeliverDma);
+  // Small batches keep the in-kernel mirror (latency: no event wake-up, no copy behind the last kernel) -- unless their
+  // results are large: a kernel that stores tens of megabytes into host memory waits for the link (one 4096^2 image with
+  // 102 k half descriptors, 28 MB: 0.76 ms against 0.47), while the copier's DMA copy of a part runs beside the next
+  // part's launch -- the same latency on one context, 15 % more images per second on three.  "Large" is judged by what the
+  // context's last batch of this size delivered (the capacity is a worst case many times the typical count): the first
+  // batch of a context uses the mirror.  HESS_MIRROR_MAX_MB (16) is the limit.
+  const size_t expect = c->last_result_batch == batch ? c->last_result_bytes : 0;
+  int d = c->delivery_pref >= 0 ? c->delivery_pref
+                                : (batch <= c->mirror_max_batch && expect <= c->mirror_max_bytes ? kDeliverMirror : kDeliverDma);
   if (d == kDeliverMirror && !c->host_fits) d = kDeliverDma;  // the mirror needs the worst case pinned up front
   if (d == kDeliverDma && copier_start(c) != 0) d = kDeliverBlit;
   c->delivery = d;
@@ -1508,6 +1536,7 @@ int submit_inner(hess_ctx* c, const PendingRun& r) {
     cp.batch = r.batch;
     cp.upload_first = false;
     cp.nparts = c->nparts;
+    cp.part_features = c->part_features;
     for (int k = 0; k < Copier::kMaxParts; k++) cp.part_end[k] = c->part_end[k];
     cp.done = false;
     cp.has_job = true;
@@ -1566,6 +1595,8 @@ int wait_inner(hess_ctx* c, const PendingRun& r) {
     c->offs[b + 1] = (size_t)hs[b + 1];
   }
   const size_t total = c->offs[batch];
+  c->last_result_bytes = total * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
+  c->last_result_batch = batch;
   if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
   if (c->dim && (rc = ensure(c, c->h_desc, (total ? total : 1) * c->dim * 4, true))) return rc;
   if (total && c->delivery == kDeliverBlit) {
@@ -1690,6 +1721,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   c->no_top_fusion = getenv("HESS_NO_TOP_FUSION") != nullptr;
   c->early_scan = getenv("HESS_EARLY_SCAN") != nullptr;
   c->no_first_fusion = getenv("HESS_NO_FIRST_FUSION") != nullptr;
+  if (const char* e = getenv("HESS_MIRROR_MAX_MB")) c->mirror_max_bytes = (size_t)std::max(0, atoi(e)) << 20;
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
   c->no_host_upload = getenv("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = getenv("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
@@ -1933,6 +1965,7 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
           cp.upload_first = true;
           cp.run = c->pend;
           cp.nparts = 1;
+          cp.part_features = false;
           cp.done = false;
           cp.has_job = true;
           cp.cv.notify_all();

@@ -460,6 +460,18 @@ __device__ __forceinline__ void quad_fma(float& acc, float coef, float w) {
   acc = fmaf(coef, wb, acc);
 }
 
+// A launch that does only a part of one image's features (a single large image delivered in parts: the copier's DMA copy
+// of part k crosses the host link while part k + 1 is computed): the image's list narrowed to features
+// [n part / den, n (part + 1) / den) -- in list order, which is the order of the packed output, so a part is one contiguous
+// range of keypoint records and descriptors (the copier thread forms the same bounds from the count it reads).
+__device__ __forceinline__ void feature_part(const DescParams& dp, int* ftotal, int* ffirst, long long* obase) {
+  if (dp.part_den > 1) {
+    const int n = *ftotal;
+    const int lo = (int)((long long)n * dp.part / dp.part_den), hi = (int)((long long)n * (dp.part + 1) / dp.part_den);
+    *ffirst += lo; *obase += lo; *ftotal = hi - lo;
+  }
+}
+
 // Host keypoint records (PyramidCU.cpp:866-906 / :1097-1137, host arithmetic) of one image, by the whole workgroup: one
 // thread per feature, 256 per pass, staged in LDS (`kst`: 256 x 24 bytes, not otherwise in use yet) and stored as
 // contiguous 8-byte pieces -- 24-byte records stored one by one from a lane of every wavefront reached the pinned host
@@ -575,8 +587,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
   __shared__ __attribute__((aligned(16))) float crow[4][DC_ROWS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y + dp.first_image;  // (a batch's descriptors may be launched in two halves, see enqueue())
-  const int ftotal = feat_total[b], ffirst = feat_first[b];
-  const long long obase = img_base[b];  // packed output: images of the batch back to back
+  int ftotal = feat_total[b], ffirst = feat_first[b];
+  long long obase = img_base[b];  // packed output: images of the batch back to back
+  feature_part(dp, &ftotal, &ffirst, &obase);
   const int nwaves = gridDim.x * 4;
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;
@@ -879,8 +892,9 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
   __shared__ __attribute__((aligned(16))) unsigned long long hist[4][PX_WAVE_U64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y + dp.first_image;
-  const int ftotal = feat_total[b], ffirst = feat_first[b];
-  const long long obase = img_base[b];
+  int ftotal = feat_total[b], ffirst = feat_first[b];
+  long long obase = img_base[b];
+  feature_part(dp, &ftotal, &ffirst, &obase);
   const int nwaves = gridDim.x * 4;
   const float rpi = (float)(4.0 / kPI);
   const int dim = dp.half_sift ? 64 : 128;

@@ -79,7 +79,7 @@ def test_bench_json_line():
     assert "configs[4]" in c4["workload"] and c4["features"] >= 65536
     assert c4["Mpix_per_s_one_context"] > 0 and c4["Mpix_per_s_three_contexts"] > 0
     r4 = c4["roofline_descriptor"]
-    assert r4["bound"] == "hbm" and r4["peak"] == 8000.0 and 0 < r4["frac"] < 1 and r4["features_per_launch"] == c4["features"]
+    assert r4["bound"] == "hbm" and r4["peak"] == 8000.0 and 0 < r4["frac"] < 1 and abs(r4["features_per_launch"] * r4["launches_per_image"] - c4["features"]) <= r4["launches_per_image"]
 
 
 def test_driver_command_is_close_to_steady_state():

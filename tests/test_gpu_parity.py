@@ -5,6 +5,8 @@ because both sides evaluate the same IEEE binary32 operation sequences (DESIGN.m
 model").  The north star's tolerance for descriptors/keypoints is 1e-4; the tests assert 0 first
 and report the max deviation if that ever fails.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -202,6 +204,18 @@ def test_parity_4096_half_topk65536(gpu_ctx_factory):
     _assert_tied_to_reference_order(g, im[None], kw, "4096x4096 half top-K 65536")
     k, d = g.fetch(0)
     assert d.shape[1] == 64
+    # A single image whose results are large (28 MB here, judged by the context's batch before) is delivered by the copier
+    # thread in four parts -- four descriptor launches over quarters of the feature list: same bytes as the in-kernel mirror
+    # of the context's first run (compared with the oracle above).
+    g.profile_enable(True)
+    g.profile_reset()
+    g.run(im[None])
+    launches = g.profile()["descriptor"]["launches"]
+    g.profile_enable(False)
+    k2, d2 = g.fetch(0)
+    if not any(v in os.environ for v in ("HESS_DELIVERY", "HESS_DESC_PARTS", "HESS_MIRROR_MAX_MB", "HESS_MIRROR_MAX_BATCH")):   # (the A/B switches choose otherwise)
+        assert launches == 4, launches
+    assert k2.tobytes() == k.tobytes() and d2.tobytes() == d.tobytes()
     # size-independent properties at full size: unit-norm descriptors, clamp, list order, top-K cut
     assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5) and d.min() >= 0.0
     raw = g.rawlist(0)
