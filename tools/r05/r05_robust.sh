@@ -6,7 +6,7 @@ OUT=gpurun_out/r05_robust; mkdir -p $OUT
 T="tests/test_gpu_parity.py tests/test_reference_inputs_gpu.py tests/test_keypoint_list_gpu.py tests/test_descriptor_order.py tests/test_shared_results.py"
 # PART=1: the first eight switches; PART=2: the others + fuzz + soak (a slow box does not finish all of it inside one 1200 s call)
 V1="HESS_DELIVERY=mirror HESS_DELIVERY=blit HESS_DELIVERY=dma HESS_CHAIN_FROM=2 HESS_CHAIN_FROM=99 HESS_NO_PAIR=1 HESS_SCATTER_SCAN=1 HESS_SCATTER_SCAN=0"
-V2="HESS_COPIER=hip HESS_DESC_XCD=0 HESS_DESC_XCD=1 HESS_DESC_XCD=3 HESS_NO_TOP_FUSION=1 HESS_NO_FIRST_FUSION=1 HESS_EARLY_SCAN=1 HESS_NO_PRIME_BATCH=1"
+V2="HESS_COPIER=hip HESS_DESC_XCD=0 HESS_DESC_XCD=1 HESS_DESC_XCD=3 HESS_NO_TOP_FUSION=1 HESS_NO_FIRST_FUSION=1 HESS_EARLY_SCAN=1 HESS_NO_PRIME_BATCH=1 HESS_MIRROR_MAX_MB=0"
 case "${PART:-0}" in 1) VS="$V1";; 2) VS="$V2";; *) VS="$V1 $V2";; esac
 for v in $VS; do
   n=$(echo $v | tr '=' '_')
