@@ -207,6 +207,7 @@ struct hess_ctx {
   size_t mirror_max_bytes = (size_t)16 << 20;  // HESS_MIRROR_MAX_MB: result bytes (of the context's last batch) up to which a small batch uses the in-kernel mirror
   size_t last_result_bytes = 0;    // keypoints + descriptors the last batch delivered, and its size
   int last_result_batch = 0;
+  bool caller_waits = false;       // inside hess_run_* (submit + wait in one call)
   int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
   int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
@@ -1503,10 +1504,12 @@ void choose_delivery(hess_ctx* c, int batch) {
   // Small batches keep the in-kernel mirror (latency: no event wake-up, no copy behind the last kernel) -- unless their
   // results are large: a kernel that stores tens of megabytes into host memory waits for the link (one 4096^2 image with
   // 102 k half descriptors, 28 MB: 0.76 ms against 0.47), while the copier's DMA copy of a part runs beside the next
-  // part's launch -- the same latency on one context, 15 % more images per second on three.  "Large" is judged by what the
-  // context's last batch of this size delivered (the capacity is a worst case many times the typical count): the first
-  // batch of a context uses the mirror.  HESS_MIRROR_MAX_MB (16) is the limit.
-  const size_t expect = c->last_result_batch == batch ? c->last_result_bytes : 0;
+  // part's launch -- 15 % more images per second on three pipelined contexts.  That needs a caller who overlaps: a batch
+  // handed over by hess_submit_* (hess_run_*, i.e. submit + wait in one call, keeps the mirror: nothing to overlap with,
+  // and through the class with pageable pixels the copier's route is 15 % slower for a 4096^2 image).  "Large" is judged by
+  // what the context's last batch of this size delivered (the capacity is a worst case many times the typical count): the
+  // first batch of a context uses the mirror.  HESS_MIRROR_MAX_MB (16) is the limit.
+  const size_t expect = (c->last_result_batch == batch && !c->caller_waits) ? c->last_result_bytes : 0;
   int d = c->delivery_pref >= 0 ? c->delivery_pref
                                 : (batch <= c->mirror_max_batch && expect <= c->mirror_max_bytes ? kDeliverMirror : kDeliverDma);
   if (d == kDeliverMirror && !c->host_fits) d = kDeliverDma;  // the mirror needs the worst case pinned up front
@@ -1909,7 +1912,9 @@ int hess_wait(hess_ctx* c) {
 
 int hess_run_device(hess_ctx* c, const void* dev_pixels, int width, int height, int pitch, size_t image_stride,
                     int batch, int format, int pixtype) {
+  if (c) c->caller_waits = true;
   int rc = hess_submit_device(c, dev_pixels, width, height, pitch, image_stride, batch, format, pixtype);
+  if (c) c->caller_waits = false;
   if (rc) return rc;
   return hess_wait(c);
 }
@@ -2034,7 +2039,9 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
 
 int hess_run_host(hess_ctx* c, const void* pixels, int width, int height, int pitch, size_t image_stride, int batch,
                   int format, int pixtype) {
+  if (c) c->caller_waits = true;   // (a synchronous call has nothing to overlap the delivery with: choose_delivery)
   int rc = hess_submit_host(c, pixels, width, height, pitch, image_stride, batch, format, pixtype);
+  if (c) c->caller_waits = false;
   if (rc) return rc;
   return hess_wait(c);
 }

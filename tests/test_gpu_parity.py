@@ -204,12 +204,13 @@ def test_parity_4096_half_topk65536(gpu_ctx_factory):
     _assert_tied_to_reference_order(g, im[None], kw, "4096x4096 half top-K 65536")
     k, d = g.fetch(0)
     assert d.shape[1] == 64
-    # A single image whose results are large (28 MB here, judged by the context's batch before) is delivered by the copier
-    # thread in four parts -- four descriptor launches over quarters of the feature list: same bytes as the in-kernel mirror
-    # of the context's first run (compared with the oracle above).
+    # A single image whose results are large (28 MB here, judged by the context's batch before), SUBMITTED asynchronously, is
+    # delivered by the copier thread in four parts -- four descriptor launches over quarters of the feature list: same bytes
+    # as the in-kernel mirror of the context's synchronous runs (compared with the oracle above).
     g.profile_enable(True)
     g.profile_reset()
-    g.run(im[None])
+    g.submit_host(im[None])
+    g.wait()
     launches = g.profile()["descriptor"]["launches"]
     g.profile_enable(False)
     k2, d2 = g.fetch(0)
