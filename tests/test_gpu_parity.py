@@ -512,3 +512,24 @@ def test_profile_bytes_are_the_layouts_of_survey_8d(gpu_ctx_factory):
     top = 0 if "HESS_NO_TOP_FUSION" in os.environ else sum(planes)
     first = 0 if "HESS_NO_FIRST_FUSION" in os.environ else planes[0]
     assert abs(p["bytes_in_lds"] - B * 8.0 * (top + first)) < 1e-6 * layout
+
+
+def test_a_submitted_pair_runs_like_a_larger_batch_with_the_same_results(gpu_ctx_factory):
+    """Two images handed over by hess_submit_* (a pipelining caller) take the level-by-level launches and the copier's
+    delivery, two images handed over by hess_run_* the chain launches and the in-kernel mirror: same bytes."""
+    imgs = np.stack([fixtures.synthetic_blobs(640, 480, i) for i in range(2)])
+    g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=1000)
+    g.run(imgs)
+    ref = [g.fetch(b) for b in range(2)]
+    for _ in range(2):
+        g.submit_host(imgs)
+        g.wait()
+        for b in range(2):
+            k, d = g.fetch(b)
+            assert k.tobytes() == ref[b][0].tobytes() and d.tobytes() == ref[b][1].tobytes()
+    o = OracleSession(threads=8, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=1000)
+    o.run(imgs)
+    for b in range(2):
+        ok, od = o.fetch(b)
+        _assert_same_features(ref[b][0], ref[b][1], ok, od, f"pair img {b}")
+    o.close()
