@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the Hessian + SIFT hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N=1: run directly)
+  python bench.py --gpus N --steps K --warmup W          (N=1: runs in this process; N>1 with no WORLD_SIZE in the
+                                                          environment: starts its own N ranks as child processes,
+                                                          hessgpu_amd/launch.py, and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W        (N>1, one rank per GPU)
+         --master-port P bench.py --gpus N --steps K --warmup W        (N>1 under a launcher, one rank per GPU)
 
 Metric (BASELINE.json): Mpixels/s end-to-end (pyramid -> descriptor) on 1920x1080 images.
 Workload: BASELINE.json configs[1] -- 1920x1080 synthetic blobs, default octaves / DoG levels, top-K = 4096 -- as
@@ -85,7 +87,22 @@ def main():
                     "1 sequential = the reference's, 2 pixel raster); default: what hess_default_params chooses")
     ap.add_argument("--octaves", type=int, default=-1, help="developer experiments only: limit the octave count (-no); "
                     "the headline workload uses the default (all 7 octaves of 1920x1080)")
+    ap.add_argument("--spawn", action="store_true", help="start the rank(s) as child processes even for --gpus 1 (the one rank then "
+                    "takes the N > 1 code path: process group, helper-thread gather; HESS_BENCH_FORCE_DIST=1)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which a self-launched job is ended (exit code 124)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # No launcher around us: be the launcher.  This process makes no GPU call (it never imports torch); the ranks are
+        # child processes (hessgpu_amd/launch.py: rendezvous environment, rank 0's JSON line relayed, worst exit code,
+        # the whole job ended when a rank dies or the time is up) -- the reference starts its workers itself too
+        # (TestWin/MultiThreadSIFT.cpp:231-244, ServerSiftGPU/ServerSiftGPU.cpp:156-194).
+        from hessgpu_amd import launch
+        env = dict(os.environ)
+        if args.gpus == 1:
+            env["HESS_BENCH_FORCE_DIST"] = "1"
+        child = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
+        sys.exit(launch.run_ranks(child, args.gpus, timeout_s=args.launch_timeout, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,7 +125,8 @@ def main():
 
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment: the launcher's rank count and --gpus must agree "
+                  "(without WORLD_SIZE set, bench.py starts its own ranks)", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
@@ -230,13 +248,18 @@ def main():
         print(f"bench.py: gather destination of every rank: {gather_dest}", file=sys.stderr)
     landing = hdist.HostLanding() if gather_dest == "host" else None
     gathered = {}
+    # N > 1: a step's exchange (wait for the context, counts to rank 0, grouped send/recv of the lists) runs on a helper
+    # thread, in step order; the submitting thread only waits for the exchange of the context it is about to reuse,
+    # pipelined_contexts steps later.  A rank that falls behind then uses up its own pipeline depth instead of stopping
+    # every rank's submissions at every step.
+    worker = hdist.GatherWorker(dev) if use_dist else None
 
     def finish(c):
         c.wait()
         counts = [c.count(b) for b in range(B)]
         if use_dist:
             keys, desc = hdist.device_feature_tensors(c, counts, dev)
-            allc, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0)
+            allc, gk, gd = hdist.gather_feature_lists(counts, keys, desc, dst=0, counts_to_dst_only=True)
             if rank == 0:
                 if landing is not None:   # the other ranks' lists into pinned host memory: the step ends where N = 1 ends
                     gk, gd = landing.land(gk, gd, own_rank=0)
@@ -251,6 +274,19 @@ def main():
 
     host_submit = [0.0, 0]   # (diagnostics) seconds the submitting thread spent inside the submit call, calls
 
+    # (tests only) "rank:step:code": that rank leaves with that exit code before submitting that step of a run_steps call
+    # of at least that many steps -- a rank that dies mid-run, for the launcher's supervision (tests/test_bench_contract_gpu.py)
+    test_exit = [int(x) for x in os.environ.get("HESS_BENCH_TEST_EXIT", "-1:0:0").split(":")]
+
+    if worker is not None:
+        def posted(c):
+            return worker.post(finish, c)
+        finished = hdist.GatherWorker.result
+    else:
+        def posted(c):
+            return c
+        finished = finish
+
     def run_steps(n, submit):
         """n steps, software-pipelined over the contexts; every step is submitted and finished inside."""
         counts = None
@@ -258,9 +294,11 @@ def main():
         for i in range(n):
             c = ctxs[i % nctx]
             if len(inflight) == nctx:
-                counts = finish(inflight.pop(0))
+                counts = finished(inflight.pop(0))
                 if stamps is not None:
                     stamps.append(time.perf_counter())
+            if rank == test_exit[0] and i == test_exit[1]:
+                os._exit(test_exit[2])
             if stamps is not None:
                 t_sub = time.perf_counter()
                 submit(c)
@@ -268,9 +306,9 @@ def main():
                 host_submit[1] += 1
             else:
                 submit(c)
-            inflight.append(c)
+            inflight.append(posted(c))
         while inflight:
-            counts = finish(inflight.pop(0))
+            counts = finished(inflight.pop(0))
             if stamps is not None:
                 stamps.append(time.perf_counter())
         return counts
@@ -414,7 +452,9 @@ def main():
                                 " (HBM); every rank's lists also in node-shared pinned host memory, mapped by rank 0" if gather_dest == "shm" else " (HBM)")
                              if use_dist else "single GPU"),
                 "input": "u8 luminance resident in HBM; results delivered to host memory",
-                **({"gather_dest": gather_dest} if use_dist else {}),
+                **({"gather_dest": gather_dest,
+                    "exchange": "helper thread per rank, in step order; counts to rank 0 only; the submitting thread waits for the "
+                                "exchange of the context it reuses"} if use_dist else {}),
                 **({"shared_result_buffers_mb": round(sum(p["bytes"] for ps in placement for p in ps) / 1e6, 1),
                     "shared_result_buffers_in_files_mb": round(sum(p["bytes"] for ps in placement for p in ps
                                                                    if not p["desc"].startswith("/dev/shm/")) / 1e6, 1)}
@@ -482,6 +522,7 @@ def main():
         else:
             os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
+        worker.close()
         tdist.barrier()
         tdist.destroy_process_group()
 

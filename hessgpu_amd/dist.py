@@ -44,13 +44,24 @@ def count_group(group=None):
     return _count_group.get(group)
 
 
-def _exchange_counts(counts, dev, world, group):
-    """all_gather of the per-image counts -> list[world][n_local] of ints."""
+def _exchange_counts(counts, dev, world, group, dst=None):
+    """all_gather of the per-image counts -> list[world][n_local] of ints.  With `dst` (a rank inside `group`) and a
+    host path for the counts (gloo), only dst collects them: the other ranks get their own row and None for the rest,
+    and do not wait for anybody -- a sender needs no count but its own."""
     local = torch.tensor(counts, dtype=torch.int32)
     side = _count_group.get(group)
     if dev.type != "cuda" or side is not None:
+        g = side if dev.type == "cuda" else group
+        if dst is not None:
+            rank = dist.get_rank(group)
+            rows = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+            gdst = dist.get_global_rank(group, dst) if group is not None else dst
+            dist.gather(local, rows, dst=gdst, group=g)
+            if rank == dst:
+                return [c.tolist() for c in rows]
+            return [list(counts) if r == rank else None for r in range(world)]
         allc = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(allc, local, group=side if dev.type == "cuda" else group)
+        dist.all_gather(allc, local, group=g)
         return [c.tolist() for c in allc]
     # no side group: through the device, with pinned buffers and asynchronous copies (a synchronous copy
     # from pageable memory stalls every stream of the device on ROCm)
@@ -67,7 +78,7 @@ def _exchange_counts(counts, dev, world, group):
     return pin_all.tolist()
 
 
-def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
+def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None, counts_to_dst_only=False):
     """Gather per-image feature lists to rank `dst`, every rank sending exactly its own records.
 
     dst       destination rank INSIDE `group` (group-local numbering; with group=None that is the global rank).
@@ -75,8 +86,11 @@ def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     counts    list[int], features per local image (same number of local images on every rank)
     keys_u8   uint8 tensor [sum(counts), 24]  (hess_keypoint records, local images back to back)
     desc_f32  float32 tensor [sum(counts), dim] or None when descriptors are off
+    counts_to_dst_only   only dst learns every rank's counts (a gather instead of an all_gather where the counts
+              travel over the host): the senders then wait for dst alone, never for each other
     Returns on dst: (all_counts [world][n_local], keys list[world] of uint8 [n_r,24],
-    desc list[world] of float32 [n_r,dim] or None); on other ranks (all_counts, None, None).
+    desc list[world] of float32 [n_r,dim] or None); on other ranks (all_counts, None, None) -- with
+    counts_to_dst_only all_counts holds the rank's own row and None elsewhere.
 
     The counts are exchanged first (every rank then knows every block size), after which rank r sends its
     n_r x 24 and n_r x dim blocks to dst with one grouped batch of point-to-point operations (RCCL: one
@@ -86,8 +100,8 @@ def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = keys_u8.device
-    all_counts = _exchange_counts(counts, dev, world, group)
-    totals = [int(sum(c)) for c in all_counts]
+    all_counts = _exchange_counts(counts, dev, world, group, dst if counts_to_dst_only else None)
+    totals = [int(sum(c)) if c is not None else -1 for c in all_counts]
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     dim = desc_f32.shape[1] if desc_f32 is not None else 0
     ops = []
@@ -110,9 +124,73 @@ def gather_feature_lists(counts, keys_u8, desc_f32, dst=0, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if dev.type == "cuda":
+            # RCCL: wait() orders the CURRENT STREAM after the transfers, the host goes on.  The send buffers are the
+            # context's own result arrays, which its next batch overwrites from another stream: the caller may only
+            # resubmit once the transfers are really over, so the host waits here (callers that care run this
+            # function on a helper thread: GatherWorker)
+            torch.cuda.current_stream(dev).synchronize()
     if rank != dst:
         return all_counts, None, None
     return all_counts, keys, desc
+
+
+class GatherWorker:
+    """One helper thread that runs the per-step exchange (wait for the context, count exchange, grouped send/recv)
+    away from the thread that submits batches: step i's exchange then overlaps the submission of steps i+1 .. and a
+    rank that falls behind holds up its own pipeline depth, not every other rank's submitting thread at every step.
+
+    Jobs run strictly in the order they were posted, so every rank issues its collectives in the same order as long
+    as every rank posts the same sequence.  post(fn, *args) -> a ticket; result(ticket) waits for that job and returns
+    fn's value or re-raises what it raised (and every later ticket then fails the same way: after a failed collective
+    the ranks are out of step for good).  The thread selects `device` first (the current device is per thread)."""
+
+    def __init__(self, device=None):
+        import queue
+        import threading
+
+        self._q = queue.Queue()
+        self._device = device
+        self._failed = None
+        self._t = threading.Thread(target=self._loop, name="hess-gather", daemon=True)
+        self._t.start()
+
+    def _loop(self):
+        if self._device is not None and self._device.type == "cuda":
+            torch.cuda.set_device(self._device)
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            fn, args, ticket = job
+            try:
+                if self._failed is not None:
+                    raise RuntimeError("an earlier exchange of this worker failed") from self._failed
+                ticket["value"] = fn(*args)
+            except BaseException as e:   # handed to whoever asks for the result
+                ticket["error"] = e
+                if self._failed is None:
+                    self._failed = e
+            ticket["done"].set()
+
+    def post(self, fn, *args):
+        import threading
+
+        ticket = {"done": threading.Event(), "value": None, "error": None}
+        self._q.put((fn, args, ticket))
+        return ticket
+
+    @staticmethod
+    def result(ticket, timeout=None):
+        if not ticket["done"].wait(timeout):
+            raise TimeoutError("exchange still running")
+        if ticket["error"] is not None:
+            raise ticket["error"]
+        return ticket["value"]
+
+    def close(self):
+        self._q.put(None)
+        self._t.join(timeout=30.0)
 
 
 class _DevArray:

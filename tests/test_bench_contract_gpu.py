@@ -110,10 +110,14 @@ def test_two_rank_control_flow_on_one_gpu(dest, tmp_path):
         env.update(HESS_SHARE_FORCE_FILE="1", HESS_SHARE_DIR=str(tmp_path))
     if dest == "host":
         env["HESS_BENCH_SHM_PREFIX"] = "no/such"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "3", "--no-profile"],
-                       capture_output=True, text=True, timeout=900, env=env)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "3", "--no-profile"]
+    if dest == "shm":   # the BARE command, as the driver runs N = 1: bench.py starts its own two ranks (hessgpu_amd/launch.py)
+        cmd = [sys.executable] + bench
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    else:               # under the launcher the contract names
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + bench
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -133,3 +137,42 @@ def test_two_rank_control_flow_on_one_gpu(dest, tmp_path):
         assert "gather destination of every rank: host" in r.stderr
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("hessbench_")]
     assert not list(tmp_path.iterdir())          # the files are gone with their contexts
+
+
+def _bare_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra)
+    return env
+
+
+def test_a_rank_that_dies_mid_run_ends_the_self_launched_job():
+    """Rank 1 of a self-launched two-rank job leaves with code 17 before its third timed step; rank 0 is then blocked in
+    the exchange of that step.  The parent ends it and reports 17 -- within seconds, not after the backend's timeout."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
+                        "--contexts", "2", "--batch", "2", "--no-profile", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=_bare_env(HESS_BENCH_BACKEND="gloo", HESS_BENCH_SAME_GPU="1", HESS_BENCH_TEST_EXIT="1:2:17"))
+    assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
+    assert "rank(s) ended non-zero [(1, 17)]" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]      # no result line from a broken job
+    assert time.monotonic() - t0 < 300
+
+
+def test_one_rank_through_the_launcher_agrees_with_the_plain_run():
+    """--gpus 1 --spawn: one child rank on the N > 1 code path (RCCL group of one, exchange on the helper thread).  Its
+    value agrees with the plain in-process N = 1 run: taking the exchange off the submitting thread costs nothing."""
+    common = ["--steps", "60", "--warmup", "10", "--no-configs4", "--no-api-leg", "--no-host-leg", "--no-cpu-baseline", "--no-profile", "--no-steady"]
+    vals = {}
+    for name, extra in (("plain", []), ("spawn", ["--spawn"]), ("plain2", []), ("spawn2", ["--spawn"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + extra,
+                           capture_output=True, text=True, timeout=600, env=_bare_env())
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+        assert d["n_gpus"] == 1
+        vals[name] = d["value"]
+        if extra:
+            assert "RCCL" in d["config"]["sharding"] and d["config"]["exchange"].startswith("helper thread")
+    plain, spawn = max(vals["plain"], vals["plain2"]), max(vals["spawn"], vals["spawn2"])
+    # (the dist path uses 6 contexts like the plain run here: FORCE_DIST keeps world == 1)
+    assert abs(spawn - plain) / plain < 0.05, vals

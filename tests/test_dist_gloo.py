@@ -152,3 +152,52 @@ def _subgroup_worker(rank, world, port, result_path):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_helper_thread_exchange_keeps_step_order_and_only_dst_learns_the_counts(tmp_path):
+    """bench.py's N > 1 step loop: every step's exchange is posted to a GatherWorker (one helper thread per rank, jobs
+    in step order), counts travel to the destination alone.  Three ranks, five steps of different sizes per rank, the
+    submitting thread posts all of them before it asks for the first result."""
+    out = str(tmp_path / "g4.npz")
+    mp.spawn(_helper_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out)
+    # step s, rank r contributes r + s records whose first byte is 16 * s + r
+    for s in range(5):
+        assert got[f"counts{s}"].tolist() == [[0 + s], [1 + s], [2 + s]]
+        assert got[f"first{s}"].tolist() == sum(([16 * s + r] * (r + s) for r in range(3)), [])
+
+
+def _helper_worker(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = hdist.GatherWorker(torch.device("cpu"))
+
+        def step(s):
+            n = rank + s
+            keys = torch.full((n, 24), 16 * s + rank, dtype=torch.uint8)
+            desc = torch.full((n, 128), float(s), dtype=torch.float32)
+            return hdist.gather_feature_lists([n], keys, desc, dst=0, counts_to_dst_only=True)
+
+        tickets = [w.post(step, s) for s in range(5)]
+        res = [hdist.GatherWorker.result(t, timeout=120) for t in tickets]
+        if rank == 0:
+            np.savez(result_path, **{f"counts{s}": np.array(r[0]) for s, r in enumerate(res)},
+                     **{f"first{s}": np.concatenate([k.numpy()[:, 0] for k in r[1]]) for s, r in enumerate(res)})
+        else:
+            for s, (allc, gk, gd) in enumerate(res):
+                assert gk is None and gd is None
+                assert allc[rank] == [rank + s] and all(allc[r] is None for r in range(world) if r != rank)
+        # a job that raises is handed to whoever asks, and every later job fails too (the ranks are out of step)
+        bad = w.post(lambda: 1 // 0)
+        after = w.post(lambda: 5)
+        with pytest.raises(ZeroDivisionError):
+            hdist.GatherWorker.result(bad, timeout=30)
+        with pytest.raises(RuntimeError):
+            hdist.GatherWorker.result(after, timeout=30)
+        w.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
