@@ -230,24 +230,34 @@ void launch_hessian(hipStream_t st, const Geom& g, int octave, const float* gaus
 void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, float* deth, int level, float norm,
                           int batch, void* zero = nullptr, size_t zero_bytes = 0);
 
-// Extrema scan, pass 1: per-row bit masks + counts (ComputeKEY_Kernel, ProgramCU.cu:657-882).
+// The scan's UNORDERED store of detections, per image `stride` records: [ntask tasks x kDetectSlots slots][cap_spill spill
+// list].  A scan task (a wavefront's strip segment; a tile of the LDS-tiled scan) fills its own slots and posts how many it
+// used in task_count (every task does, so the array needs no clearing); what a task finds beyond its slots goes to the
+// image's spill list under spill_count (arrives zeroed).
+constexpr int kDetectSlots = 64;
+struct DetectStore {
+  RawKey* found;
+  long long stride;     // records per image
+  int ntask;
+  int* task_count;      // [batch][ntask]
+  int* spill_count;     // [batch]
+  int cap_spill;
+  unsigned* hist;       // [batch][kHistBins] top-K key histogram, or null
+};
+int extrema_tasks(const Geom& g);  // scan tasks per image for this geometry (depends on Geom::stream_rows)
+// Extrema scan (ComputeKEY_Kernel, ProgramCU.cu:657-882): every accepted pixel as a complete RawKey in the image's
+// unordered store, its bit in the row's mask words, its row's count, and -- ds.hist != null -- the top-K key histogram.
+// rowmask, rowcnt, ds.spill_count, ds.hist arrive zeroed.
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch,
-                         int first_block = 0, int nblocks = 0);  // (a range of the image's streaming workgroups; 0, 0 = all)
-bool extrema_streams(const Geom& g);  // the streaming scan (and with it the range form) applies to this geometry
-// Exclusive scan of the row counts per image, level totals, -tc level truncation
-// (GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278).
-void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt,
-                     int* rowoff, int* level_count, int* raw_total, int cap_raw, int* overflow,
-                     int batch);
-// Extrema scan, pass 2: row counts -> exclusive offsets in list order (level totals, -tc level truncation:
-// GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278) and the ordered scatter
-// of the detections into the raw list.  Images of up to 8192 rows: one launch (every scatter workgroup scans the counts
-// in LDS); larger ones: row_scan_kernel first (rowoff in HBM).
-void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const LimitParams& lp, const float* gauss,
-                            const float* deth, const uint64_t* rowmask, const int* rowcnt, int* rowoff, int* level_count,
-                            int* raw_total, int* overflow, RawKey* raw, int cap_raw, int batch,
-                            unsigned* hist = nullptr, int topk = 0);  // hist: top-K key histogram, counted on the way
+                         const float* deth, uint64_t* rowmask, int* rowcnt, const DetectStore& ds, int batch);
+bool extrema_streams(const Geom& g);  // the streaming scan applies to this geometry
+// List order (ListGen_Kernel, ProgramCU.cu:924-1051, made deterministic): row counts -> exclusive offsets in list order
+// (level totals, -tc level truncation: GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368,
+// SiftPyramid.cpp:201-278) by the image's first workgroup, and every detection copied to offset(row) + mask bits to its
+// left: the raw list in (level, row, col) order.  ticket, flag: one int per image each, arrive zeroed.
+void launch_extrema_place(hipStream_t st, const Geom& g, const LimitParams& lp, const DetectStore& ds, const uint64_t* rowmask,
+                          const int* rowcnt, int* rowoff, int* level_count, int* raw_total, int* overflow, int* ticket,
+                          int* flag, RawKey* raw, int cap_raw, int batch);
 
 // Top-K (SelectTopK, PyramidCU.cpp:1881-1987): keeps the K largest abs(half(response)), ties to
 // the lower list index, order preserved; when total < K the list is copied.  One launch (ticketed chunks with a
@@ -273,7 +283,7 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
                        int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
                        const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
-                       float* desc, int cap_feat, int batch);
+                       float* desc, int cap_feat, int batch, int seen_features = 0);
 // Exclusive prefix of the per-image feature totals: img_base[0..batch] (packed output layout).
 // Device evaluation of the elementary functions for the parity tests.
 void launch_math_probe(hipStream_t st, int which, const float* a, const float* b, float* out, int n);

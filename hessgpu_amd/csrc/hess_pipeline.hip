@@ -167,14 +167,16 @@ struct hess_ctx {
   bool use_topk = false, multi = false;
   int dim = 0;
   // device buffers (grow-only, like CuTexImage::InitTexture)
-  DevBuf gauss, deth, got, input_f32, upsampled, stage, rowoff, level_count, raw_total, raw, sel,
+  int found_tasks = 0;  // scan tasks per image the detection store is laid out for (plan)
+  DevBuf gauss, deth, got, input_f32, upsampled, stage, rowoff, level_count, raw_total, found, task_count, raw, sel,
       sel_total, recs, ocount, foffset, fsrc, feat_total, feat_first, img_base, keys, desc;
   // Everything the detection stages expect zeroed lives in one allocation and is cleared by one fill per batch:
-  // overflow flags, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
+  // overflow flags, detection counters, per-row counts, the top-K histogram, the extrema bit masks (views into `zeroed`).
   DevBuf zeroed;
   size_t zeroed_used = 0;
   bool zero_filled = false;  // the running batch's det-H launch has cleared `zeroed`
-  struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist, tk;  // tk: tickets, chunk words, per-level counts of the top-K launch
+  struct View { void* p = nullptr; } rowmask, rowcnt, overflow, hist, tk,  // tk: tickets, chunk words, per-level counts of the top-K launch
+      found_count, place_ticket, place_flag;                                // detections found per image; extrema_place_kernel's ticket and flag per image
   // host results
   int batch = 0;          // images whose results the context holds (0 after a failed or while a pending run: hess_count /
                           // hess_fetch / hess_device_results refuse instead of handing out the run before)
@@ -211,10 +213,10 @@ struct hess_ctx {
   int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
   int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
+  int seen_features = 0;           // largest per-image feature count of the last finished batch (0: none yet): sizes the descriptor grid
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
   bool no_pair = false;            // HESS_NO_PAIR: one launch per pyramid level (A/B switch)
   bool no_first_fusion = false;    // HESS_NO_FIRST_FUSION: level 0 of octave 0 from a launch of its own, written to HBM (A/B switch)
-  bool early_scan = false;         // HESS_EARLY_SCAN: octave 0's extrema scan right behind octave 0's last pyramid launch (A/B switch)
   bool no_top_fusion = false;      // HESS_NO_TOP_FUSION: the top level is stored and its det-H made by a launch of its own (A/B switch)
   bool keep_levels = false;        // hess_debug_keep_levels: the top Gaussian level of every octave is written to HBM as well
   int chain_from = 0;              // HESS_CHAIN_FROM: first octave produced by one level-chain launch (0: by batch size; 99: none)
@@ -581,13 +583,14 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if (ds < 0 && (rc = ensure(c, c->upsampled, (size_t)B * ws * hs * 4))) return rc;
   {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_cnt = 256, o_hist = o_cnt + up((size_t)B * g.NR * 4);
+    const size_t o_found = 256, o_cnt = o_found + up((size_t)3 * B * 4), o_hist = o_cnt + up((size_t)B * g.NR * 4);
     const size_t o_mask = o_hist + (c->use_topk ? up((size_t)B * kHistBins * 4) : 0);
     const size_t o_tk = o_mask + up((size_t)B * g.NM * 8);
     c->zeroed_used = o_tk + (c->use_topk ? up(topk_scratch_bytes(cap_raw, B, g.nlev)) : 0);
     if ((rc = ensure(c, c->zeroed, c->zeroed_used))) return rc;
     char* z = (char*)c->zeroed.p;
     c->overflow.p = z; c->rowcnt.p = z + o_cnt; c->hist.p = z + o_hist; c->rowmask.p = z + o_mask; c->tk.p = z + o_tk;
+    c->found_count.p = z + o_found; c->place_ticket.p = z + o_found + (size_t)B * 4; c->place_flag.p = z + o_found + (size_t)2 * B * 4;
   }
   if ((rc = ensure(c, c->rowoff, (size_t)B * g.NR * 4))) return rc;
   if ((rc = ensure(c, c->level_count, (size_t)B * g.nlev * 4))) return rc;
@@ -597,6 +600,19 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   if ((rc = ensure(c, c->feat_first, (size_t)B * 4))) return rc;
   if ((rc = ensure(c, c->img_base, (size_t)(B + 1) * 4))) return rc;
   if ((rc = ensure(c, c->raw, (size_t)B * cap_raw * sizeof(RawKey)))) return rc;
+  {  // the scan's unordered detections: every scan task's slots + the image's spill list (hess_dev.h, DetectStore);
+     // tasks for the shortest segments a batch may be scanned with (enqueue(): batches of one or two images, HESS_STREAM_ROWS)
+    int ntask = extrema_tasks(g);
+    for (int rows : {kStreamRows / 2, c->stream_rows}) {
+      if (rows <= 0) continue;
+      Geom gr = g;
+      set_stream_rows(gr, rows);
+      ntask = std::max(ntask, extrema_tasks(gr));
+    }
+    c->found_tasks = ntask;
+    if ((rc = ensure(c, c->found, (size_t)B * ((size_t)ntask * kDetectSlots + cap_raw) * sizeof(RawKey)))) return rc;
+    if ((rc = ensure(c, c->task_count, (size_t)B * ntask * 4))) return rc;
+  }
   if (c->use_topk) {
     if ((rc = ensure(c, c->sel, (size_t)B * cap_sel * sizeof(RawKey)))) return rc;
   }
@@ -727,16 +743,6 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   Geom gx = g;  // the extrema scan's segment length
   if (c->stream_rows > 0) set_stream_rows(gx, c->stream_rows);      // HESS_STREAM_ROWS (A/B switch; a multiple of 3)
   else if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);        // one or two images: shorter segments, twice the wavefronts
-  // HESS_EARLY_SCAN=1 (A/B switch): octave 0's part of the extrema scan right behind the launch that completes octave 0's
-  // det-H planes, while the last of them may still be in the last-level cache, instead of after the whole pyramid
-  int scanned_blocks = 0;
-  auto early_scan = [&]() {
-    if (!c->early_scan || user_mode || batch < 3 || g.noct < 2 || !extrema_streams(gx) || !c->zero_filled || scanned_blocks) return;
-    double det_bytes = 4.0 * s.level_num * g.o[0].plane;
-    ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
-    scanned_blocks = gx.o[1].stream_base;
-    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch, 0, scanned_blocks);
-  };
   if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
   // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
   const bool direct_u8 = (format == HESS_FMT_LUM && pixtype == HESS_PIX_U8 && c->ds == 0 && c->has_taps0 &&
@@ -898,7 +904,6 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
           if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
           else { launch_level(ja); launch_level(jb); }
         }
-        if (top_o == 0) early_scan();
         deferred_o = -1;
         continue;
       }
@@ -954,20 +959,28 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   lp.threshold = p.feature_count_threshold;
   if (!c->zero_filled)  // overflow flags, row counts, histogram, masks (normally cleared by octave 0's top-level launch)
     HIP_TRY(c, hipMemsetAsync(c->zeroed.p, 0, c->zeroed_used, st));
+  DetectStore dstore;
+  dstore.found = (RawKey*)c->found.p;
+  dstore.ntask = extrema_tasks(gx);
+  dstore.stride = (long long)c->found_tasks * kDetectSlots + c->cap_raw;
+  dstore.task_count = (int*)c->task_count.p;
+  dstore.spill_count = (int*)c->found_count.p;
+  dstore.cap_spill = c->cap_raw;
+  dstore.hist = c->use_topk ? (unsigned*)c->hist.p : nullptr;
+  if (dstore.ntask > c->found_tasks) { set_err(c, "detection store laid out for %d scan tasks, the batch has %d", c->found_tasks, dstore.ntask); return HESS_ERR_ARG; }
   {
     // algorithmic bytes: every det-H level of every octave is read once (4 B R per level-pixel)
     double det_bytes = 0;
-    for (int o = scanned_blocks ? 1 : 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
+    for (int o = 0; o < g.noct; o++) det_bytes += 4.0 * s.level_num * g.o[o].plane;
     ProfScope ps(c, HESS_K_EXTREMA, det_bytes * batch);
-    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, batch, scanned_blocks, 0);
+    launch_extrema_mark(st, gx, dp, gauss, deth, (uint64_t*)c->rowmask.p, (int*)c->rowcnt.p, dstore, batch);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[2], st));
   {
     ProfScope ps(c, HESS_K_EXTREMA, 0.0);
-    launch_extrema_scatter(st, g, dp, lp, gauss, deth, (const uint64_t*)c->rowmask.p, (const int*)c->rowcnt.p,
-                           (int*)c->rowoff.p, (int*)c->level_count.p, (int*)c->raw_total.p, (int*)c->overflow.p,
-                           (RawKey*)c->raw.p, c->cap_raw, batch, c->use_topk ? (unsigned*)c->hist.p : nullptr,
-                           p.feature_count_threshold);
+    launch_extrema_place(st, g, lp, dstore, (const uint64_t*)c->rowmask.p, (const int*)c->rowcnt.p, (int*)c->rowoff.p,
+                         (int*)c->level_count.p, (int*)c->raw_total.p, (int*)c->overflow.p, (int*)c->place_ticket.p,
+                         (int*)c->place_flag.p, (RawKey*)c->raw.p, c->cap_raw, batch);
   }
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[3], st));
   // ---- top-K (LimitFeatureCount(0) -> SelectTopK) ----
@@ -1052,7 +1065,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       dsp.part_den = c->part_features ? c->nparts : 1;
       launch_descriptor(st, g, dsp, list, cap_list, (const FRec*)c->recs.p, (const int*)c->fsrc.p,
                         (const int*)c->feat_total.p, (const int*)c->feat_first.p, (const int*)c->img_base.p, got,
-                        (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, c->part_end[k] - first);
+                        (HostKeypoint*)c->keys.p, c->dim ? (float*)c->desc.p : nullptr, c->cap_feat, c->part_end[k] - first,
+                        c->seen_features);
       if (k < c->nparts - 1) HIP_TRY(c, hipEventRecord(c->cp.ev_part[k], st));
       if (!c->part_features) first = c->part_end[k];
     }
@@ -1600,6 +1614,7 @@ int wait_inner(hess_ctx* c, const PendingRun& r) {
     c->offs[b + 1] = (size_t)hs[b + 1];
   }
   const size_t total = c->offs[batch];
+  c->seen_features = batch ? *std::max_element(c->counts.begin(), c->counts.end()) : 0;
   c->last_result_bytes = total * (sizeof(HostKeypoint) + (size_t)c->dim * 4);
   c->last_result_batch = batch;
   if ((rc = ensure(c, c->h_keys, (total ? total : 1) * sizeof(HostKeypoint), true))) return rc;
@@ -1724,7 +1739,6 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   if (const char* ci = getenv("HESS_INITIAL_CAP")) c->cap_init = atoi(ci) > 0 ? atoi(ci) : 0;
   c->no_pair = getenv("HESS_NO_PAIR") != nullptr;
   c->no_top_fusion = getenv("HESS_NO_TOP_FUSION") != nullptr;
-  c->early_scan = getenv("HESS_EARLY_SCAN") != nullptr;
   c->no_first_fusion = getenv("HESS_NO_FIRST_FUSION") != nullptr;
   if (const char* e = getenv("HESS_MIRROR_MAX_MB")) c->mirror_max_bytes = (size_t)std::max(0, atoi(e)) << 20;
   if (const char* cf = getenv("HESS_CHAIN_FROM")) c->chain_from = atoi(cf);
@@ -1742,7 +1756,7 @@ void hess_destroy(hess_ctx* c) {
   copier_stop(c);
   stager_stop(c->sg);
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
-                    &c->level_count, &c->raw_total, &c->raw, &c->sel, &c->sel_total,
+                    &c->level_count, &c->raw_total, &c->found, &c->task_count, &c->raw, &c->sel, &c->sel_total,
                     &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
                     &c->keys, &c->desc};
   // A poisoned context (a DMA copy that was lost may still be in flight or land late) deliberately leaks the copy's

@@ -5,19 +5,23 @@
 // key map + ListGen_Kernel second pass (:924-1051), DetectionData* host round trips (:3057-3079)
 // and the bitonic-sort/Blelloch top-K chain (:2205-3051).
 //
-// Structure (no key map, no atomics on the list, no host round trip):
+// Structure (no key map, no host round trip, every candidate evaluated ONCE):
 //   hessian_rows4  det-H of the octave's top level (the other levels come fused out of the Gaussian
 //                  launches, k_gauss.hip); hessian_kernel is the general one-row form (det-H + gradient);
-//   extrema_stream pass 1 (dog <= 5): register-streaming 26-neighbour scan, candidates queued for the
-//                  reference's exact test, positional mask bits + row counts (extrema_mark: LDS-tiled
-//                  variant for larger level counts / planes);
-//   row_scan       one workgroup per image: exclusive scan of the row counts in list order
-//                  (level, row) -> row offsets, level totals, -tc level truncation;
-//   extrema_scatter pass 2, one thread per detection: row by binary search in the offsets, column = k-th
-//                  set bit of the row's mask words, keypoint recomputed, written at its list position:
-//                  (level,row,col) order, deterministic;
+//   extrema_stream the scan (dog <= 5): register-streaming 26-neighbour filter, candidates queued for the
+//                  reference's exact test; an accepted pixel is written -- complete, as a RawKey -- to the image's
+//                  UNORDERED list of detections (one wave-aggregated atomic per batch of candidates), sets its
+//                  positional bit in the row's mask words, counts in its row and in the top-K key histogram
+//                  (extrema_mark: LDS-tiled variant for larger level counts / planes);
+//   extrema_place  list order: the first workgroup of an image to arrive scans the row counts in list order (level,
+//                  row) -> row offsets, level totals, -tc level truncation; every detection's position is its row's
+//                  offset + the number of mask bits below its column (computed while the scan is awaited): the
+//                  (level, row, col) order of the raw list, deterministic, with one 32-byte copy per detection;
 //   topk           15-bit histogram of abs(half(response)) -> exact cut, then one ordered
 //                  compaction pass (ties at the cut resolved towards the lower list index).
+// (Rounds 1-5 marked the pixels in the scan and evaluated every detection a second time in an ordered scatter pass:
+//  row_scan_kernel + extrema_scatter_kernel, 63 us and 128 MB of det-H re-reads per step of eight 1080p images.)
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 
@@ -151,7 +155,7 @@ struct KeyVal {
 template <bool PRE = false>
 __device__ __forceinline__ bool key_eval(const float* texC, const float* texP, const float* texN,
                                          const float* texG, int width, int index, const DetectParams& dp,
-                                         KeyVal* out) {
+                                         KeyVal* out, long long gindex = -1) {
   float d00, d01, d02, d10, d11, d12, d20, d21, d22;
   float p00, p01, p02, p10, p11, p12, p20, p21, p22;
   float n00, n01, n02, n10, n11, n12, n20, n21, n22;
@@ -224,7 +228,8 @@ __device__ __forceinline__ bool key_eval(const float* texC, const float* texP, c
     uint32_t type;  // ProgramCU.cu:828-851
     if (response < 0) type = 2u;
     else {
-      const float g0 = texG[i1 - 1], g1 = texG[i1], g2 = texG[i1 + 1];
+      const long long gi = gindex >= 0 ? gindex : (long long)i1;  // (texG may have its own pitch: the LDS-tiled scan)
+      const float g0 = texG[gi - 1], g1 = texG[gi], g2 = texG[gi + 1];
       const float Lxx = fmaf(-2.0f, g1, g0) + g2;
       type = (Lxx > 0) ? 0u : 1u;
     }
@@ -232,6 +237,55 @@ __device__ __forceinline__ bool key_eval(const float* texC, const float* texP, c
     out->dx = dx; out->dy = dy; out->ds = ds;
   }
   return true;
+}
+
+// Where an image's detections go.  Every scan task (a wavefront's strip segment, or a tile of the LDS-tiled scan) owns
+// DT_SLOTS slots of the image's UNORDERED detection store -- no atomic to claim them, the task counts for itself; what a
+// task finds beyond its slots goes to the image's shared spill list (one atomic per wavefront call, rare).  List order is
+// rebuilt from the row's positional mask bits and count (extrema_place_kernel).
+constexpr int DT_SLOTS = kDetectSlots;
+struct DetectSink {
+  RawKey* slots;              // this task's DT_SLOTS slots
+  RawKey* spill;              // [cap_spill] of this image
+  int* spill_count;           // of this image (arrives zeroed)
+  int cap_spill;
+  unsigned long long* mask;   // this image's mask words
+  int* rowcnt;                // this image's row counts
+  unsigned* hist;             // this image's histogram of abs(half(response)) (null: no top-K)
+};
+
+// One accepted detection per lane (`ok`, m = its ballot), called by the whole wavefront; `before` = detections of the
+// task before this call (wavefront-uniform).  Every lane writes its own complete record.
+__device__ __forceinline__ void post_detections(const DetectSink& sk, int before, bool ok, uint64_t m, const KeyVal& kv,
+                                                int level_index, int row, int col, long long mask_word, int row_index) {
+  if (!m) return;
+  const int idx = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  const int nspill = before + __popcll(m) - max(before, DT_SLOTS);  // (uniform) of this call's detections, those past the slots
+  int sbase = 0;
+  if (nspill > 0) {
+    const int lane = threadIdx.x & 63, first = __builtin_ctzll(m);
+    if (lane == first) sbase = atomicAdd(sk.spill_count, nspill);
+    sbase = __shfl(sbase, first);
+  }
+  if (ok) {
+    RawKey* dstk = nullptr;
+    if (idx < DT_SLOTS) dstk = sk.slots + idx;
+    else {
+      const int j = sbase + idx - max(before, DT_SLOTS);
+      // (more than cap: the row counts say so, the host grows the lists and runs the batch again)
+      if (j < sk.cap_spill) dstk = sk.spill + j;
+    }
+    if (dstk) {
+      uint4* const dst = reinterpret_cast<uint4*>(dstk);
+      dst[0] = make_uint4((uint32_t)level_index, (uint32_t)col, (uint32_t)row, kv.packed);
+      dst[1] = make_uint4(__float_as_uint(kv.dx), __float_as_uint(kv.dy), __float_as_uint(kv.ds), 0u);
+    }
+    atomicOr(&sk.mask[mask_word], 1ull << (col & 63));
+    atomicAdd(&sk.rowcnt[row_index], 1);
+    // histogram of the top-K selection key abs(half(response)), 15 bits (topk_select_kernel): counted here, where the
+    // response has just been computed
+    if (sk.hist) atomicAdd(&sk.hist[(kv.packed >> 16) & 0x7fffu], 1u);
+  }
 }
 
 struct RowTask {
@@ -267,11 +321,11 @@ __device__ __forceinline__ RowTask decode_row(const Geom& g, int wave, int batch
 // by the scatter pass is independent of the order candidates were queued in.
 constexpr int EX_TR = 4, EX_TC = 128, EX_STRIDE = EX_TC + 8 + 4;  // cols x0-4 .. x0+260, +4 pad
 
-__global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* deth,
-                                                           uint64_t* rowmask, int* rowcnt) {
+__global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams dp, const float* gauss, const float* deth,
+                                                           uint64_t* rowmask, int* rowcnt, DetectStore ds) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [dog+2][EX_TR+2][EX_STRIDE]
+  __shared__ int nfound;  // detections of this tile so far (all levels)
   __shared__ unsigned short cand[EX_TR * EX_TC];
-  __shared__ unsigned long long mwords[EX_TR][EX_TC / 64];
   __shared__ int ncand;
   const int b = blockIdx.y;
   int o = 0;
@@ -312,10 +366,15 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
       if (dst[u] >= 0) *reinterpret_cast<float4*>(&tile[dst[u]]) = v[u];
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) nfound = 0;
+  const long long fbase = (long long)b * ds.stride;
+  const DetectSink sk{ds.found + fbase + (long long)blockIdx.x * DT_SLOTS, ds.found + fbase + (long long)ds.ntask * DT_SLOTS,
+                      ds.spill_count + b, ds.cap_spill, reinterpret_cast<unsigned long long*>(rowmask) + (long long)b * g.NM,
+                      rowcnt + (long long)b * g.NR, ds.hist ? ds.hist + (long long)b * kHistBins : nullptr};
   for (int l = 1; l <= g.dog; l++) {
+    __syncthreads();  // the previous level's candidates have been processed
     if (threadIdx.x == 0) ncand = 0;
-    if (threadIdx.x < EX_TR * (EX_TC / 64)) (&mwords[0][0])[threadIdx.x] = 0ull;
-    __syncthreads();  // also orders stage 0 (first level) / the previous level's write-out
+    __syncthreads();  // also orders stage 0 (first level)
     const float* C = tile + (l * ROWS) * EX_STRIDE;
     const float* P = C - ROWS * EX_STRIDE;
     const float* N = C + ROWS * EX_STRIDE;
@@ -356,26 +415,29 @@ __global__ __launch_bounds__(256) void extrema_mark_kernel(Geom g, DetectParams 
       }
     }
     __syncthreads();
-    // ---- stage 2: one candidate per lane ----
+    // ---- stage 2: one candidate per lane; accepted ones go to the image's list, mask words and row counts ----
     const int nc = ncand;
-    for (int i = threadIdx.x; i < nc; i += 256) {
-      const int code = cand[i];
+    const float* G = gauss + og.lvl_off + ((long long)l * g.B + b) * og.plane;
+    for (int i0 = 0; i0 < nc; i0 += 256) {  // (whole wavefronts go round: post_detections is a wavefront call)
+      const int i = i0 + threadIdx.x;
+      const int code = cand[i < nc ? i : 0];
       const int rl_ = code >> 8, cl = code & 255;
-      if (key_eval<false>(C, P, N, nullptr, EX_STRIDE, (rl_ + 1) * EX_STRIDE + (cl + 4), dp, nullptr))
-        atomicOr(&mwords[rl_][cl >> 6], 1ull << (cl & 63));
-    }
-    __syncthreads();
-    // ---- write-out: mask words and row counts of this level ----
-    if (threadIdx.x < EX_TR * (EX_TC / 64)) {
-      const int rl_ = threadIdx.x / (EX_TC / 64), blk = threadIdx.x % (EX_TC / 64);
-      const int row = y0 + rl_;
-      if (row < og.h && x0 + blk * 64 < og.wa) {
-        const unsigned long long m = mwords[rl_][blk];
-        rowmask[(long long)b * g.NM + og.mask_base + ((l - 1) * og.h + row) * og.w64 + (x0 >> 6) + blk] = m;
-        if (m) atomicAdd(&rowcnt[(long long)b * g.NR + og.row_base + (l - 1) * og.h + row], __popcll(m));
+      const int row = y0 + rl_, col = x0 + cl;
+      KeyVal kv;
+      const bool ok = i < nc && key_eval<false>(C, P, N, G, EX_STRIDE, (rl_ + 1) * EX_STRIDE + (cl + 4), dp, &kv,
+                                                (long long)row * og.wa + col);
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      int before = 0;
+      if (m) {  // (wavefront-uniform) the tile's four wavefronts count in LDS
+        if (lane == __builtin_ctzll(m)) before = atomicAdd(&nfound, __popcll(m));
+        before = __shfl(before, __builtin_ctzll(m));
       }
+      post_detections(sk, before, ok, m, kv, o * g.dog + (l - 1), row, col,
+                      og.mask_base + ((l - 1) * og.h + row) * og.w64 + (col >> 6), og.row_base + (l - 1) * og.h + row);
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) ds.task_count[(long long)b * ds.ntask + blockIdx.x] = min(nfound, DT_SLOTS);
 }
 
 // ---- streaming extrema scan (pass 1, default for dog <= 5): registers instead of an LDS tile ----
@@ -400,14 +462,14 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
 template <int DOG>
-__global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParams dp, const float* deth,
-                                                             unsigned long long* rowmask, int* rowcnt, int block0) {
+__global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParams dp, const float* gauss, const float* deth,
+                                                             unsigned long long* rowmask, int* rowcnt, DetectStore ds) {
   constexpr int NLV = DOG + 2;
   constexpr int NC = kStreamCols;  // columns per lane
   __shared__ uint32_t queue[4][SX_QCAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  const int blk = (int)blockIdx.x + block0;  // (a launch may cover a range of the image's workgroups: launch_extrema_mark)
+  const int blk = (int)blockIdx.x;
   int o = 0;
   for (int k = 1; k < g.noct; k++)
     if (g.o[k].stream_base <= blk) o = k;
@@ -415,7 +477,11 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
   const int task = (blk - og.stream_base) * 4 + wv;
   const int seg = task / og.strips, strip = task - seg * og.strips;
   const int ys = seg * g.stream_rows;
-  if (ys >= og.h) return;  // wavefront-uniform; the kernel has no workgroup barrier
+  int* const my_count = ds.task_count + (long long)b * ds.ntask + blk * 4 + wv;  // every task posts its count, also an idle one
+  if (ys >= og.h) {  // wavefront-uniform; the kernel has no workgroup barrier
+    if (lane == 0) *my_count = 0;
+    return;
+  }
   const int ye = min(ys + g.stream_rows, og.h);
   const int cx = strip * SX_PITCH - NC + NC * lane;  // this lane's first column
   const bool col_in = cx >= 0 && cx < og.wa;         // (wa is a multiple of 4: a lane's columns are all in or all out)
@@ -447,14 +513,21 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
       }
     }
   };
-  auto process = [&](uint32_t e, bool active) {
+  const long long fbase = (long long)b * ds.stride;
+  const DetectSink sk{ds.found + fbase + (long long)(blk * 4 + wv) * DT_SLOTS, ds.found + fbase + (long long)ds.ntask * DT_SLOTS,
+                      ds.spill_count + b, ds.cap_spill, rowmask + (long long)b * g.NM, rowcnt + (long long)b * g.NR,
+                      ds.hist ? ds.hist + (long long)b * kHistBins : nullptr};
+  const float* gbase = gauss + og.lvl_off + (long long)b * og.plane;
+  int nfound = 0;  // detections of this task so far (wavefront-uniform)
+  auto process = [&](uint32_t e, bool active) {  // (called by the whole wavefront)
     const int l = e >> 28, row = (e >> 14) & 0x3FFF, col = e & 0x3FFF;
     const float* C = base + l * lstep;
-    if (active && key_eval<false>(C, C - lstep, C + lstep, nullptr, wa, row * wa + col, dp, nullptr)) {
-      atomicOr(&rowmask[(long long)b * g.NM + og.mask_base + ((l - 1) * h + row) * og.w64 + (col >> 6)],
-               1ull << (col & 63));
-      atomicAdd(&rowcnt[(long long)b * g.NR + og.row_base + (l - 1) * h + row], 1);
-    }
+    KeyVal kv;
+    const bool ok = active && key_eval<false>(C, C - lstep, C + lstep, gbase + l * lstep, wa, row * wa + col, dp, &kv);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+    post_detections(sk, nfound, ok, m, kv, o * g.dog + (l - 1), row, col, og.mask_base + ((l - 1) * h + row) * og.w64 + (col >> 6),
+                    og.row_base + (l - 1) * h + row);
+    nfound += __popcll(m);
   };
 
   // ring of the last three rows: horizontal 3-max/3-min of every level (centre included) and the raw centre values of
@@ -550,203 +623,10 @@ __global__ __launch_bounds__(256) void extrema_stream_kernel(Geom g, DetectParam
   }
   __builtin_amdgcn_wave_barrier();
   if (qn > 0) process(q[lane < qn ? lane : 0], lane < qn);
+  if (lane == 0) *my_count = min(nfound, DT_SLOTS);
 }
 
-// Extrema scan pass 2: one thread per detection.  Thread i of image b finds its row by binary search
-// in the exclusive row offsets, its column as the (i - offset)-th set bit of the row's mask words,
-// recomputes the keypoint (all lanes busy) and writes raw[i]: row-major order by construction.
 __device__ int apply_level_limits(int* lc, int nlev, const LimitParams& lp, bool generation_stage);
-
-// Rows per image up to which the scatter pass scans the row counts itself, in LDS (1080p: 6 423 rows; a 4096^2 image has
-// 24 552 and keeps the separate row_scan_kernel).
-constexpr int SC_MAXROWS = 8192;
-
-// SCAN = true: every workgroup first turns the image's row counts into exclusive offsets in LDS -- level totals, the
-// -tc level rules, one workgroup scan, exactly row_scan_kernel's steps -- instead of reading the offsets a launch of
-// its own would have left in HBM: a single-workgroup kernel (12 us) less in the batch's dependent chain for 2 - 3 us
-// of redundant work per workgroup on L2-resident counts; the searches below then run on LDS.  Workgroup 0 of the
-// image posts the totals (raw_total, level_count, the overflow word).
-template <bool SCAN>
-__global__ __launch_bounds__(256) void extrema_scatter_kernel(Geom g, DetectParams dp, LimitParams lp, const float* gauss,
-                                                              const float* deth, const uint64_t* rowmask,
-                                                              const int* rowoff_or_cnt, int* raw_total, int* level_count,
-                                                              int* overflow, RawKey* raw, int cap_raw, unsigned* hist,
-                                                              int topk) {
-  __shared__ int s_off[SCAN ? SC_MAXROWS : 1];
-  __shared__ int s_lc[kMaxOct * kMaxDog], s_keep[kMaxOct * kMaxDog], s_h[kMaxOct], s_base[kMaxOct], s_wsum[4], s_total;
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  int n;
-  const int* off;
-  if (SCAN) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int* cnt = rowoff_or_cnt + (long long)b * g.NR;
-    constexpr int RC = SC_MAXROWS / 256;  // rows per thread at most
-    {  // counts -> LDS, coalesced; all loads of a thread in flight before its first LDS store (the counts are L2-resident)
-      int v[RC];
-#pragma unroll
-      for (int u = 0; u < RC; u++) v[u] = (tid + u * 256 < g.NR) ? cnt[tid + u * 256] : 0;
-#pragma unroll
-      for (int u = 0; u < RC; u++) if (tid + u * 256 < g.NR) s_off[tid + u * 256] = v[u];
-    }
-    for (int k = tid; k < g.nlev; k += 256) s_lc[k] = 0;
-    if (tid < g.noct) { s_h[tid] = g.o[tid].h; s_base[tid] = g.o[tid].row_base; }
-    __syncthreads();
-    // a thread owns `per` consecutive rows of the list order, held in registers; the level of a row follows from
-    // walking the level boundaries (levels are consecutive in list order)
-    const int per = (g.NR + 255) >> 8;
-    const int r0 = min(tid * per, g.NR), r1 = min(g.NR, r0 + per);
-    int cc[RC], lis[RC];
-#pragma unroll
-    for (int u = 0; u < RC; u++) cc[u] = (u < per && r0 + u < r1) ? s_off[r0 + u] : 0;
-    {
-      int o = 0;
-      const int rq = min(r0, g.NR - 1);
-      for (int k = 1; k < g.noct; k++) if (s_base[k] <= rq) o = k;
-      const int rel = rq - s_base[o];
-      int lm = rel / s_h[o];
-      int li = o * g.dog + lm, left = s_h[o] - (rel - lm * s_h[o]), oo = o;  // rows left in the level, this one included
-#pragma unroll
-      for (int u = 0; u < RC; u++) {
-        lis[u] = li;
-        if (--left == 0) {
-          li++;
-          if (++lm == g.dog) { lm = 0; oo++; }
-          left = oo < g.noct ? s_h[oo] : 0x7fffffff;
-        }
-      }
-    }
-    // level totals (the -tc rules work on them; without a rule every level stays and only workgroup 0, which posts the
-    // totals, needs them)
-    const bool limits = lp.threshold > 0 && lp.method != 3;
-    if (limits || blockIdx.x == 0) {  // (workgroup-uniform)
-      int run_level = -1, run = 0;
-#pragma unroll
-      for (int u = 0; u < RC; u++) {
-        if (cc[u]) {
-          if (lis[u] != run_level) {
-            if (run) atomicAdd(&s_lc[run_level], run);
-            run_level = lis[u]; run = 0;
-          }
-          run += cc[u];
-        }
-      }
-      if (run) atomicAdd(&s_lc[run_level], run);
-      __syncthreads();
-      if (tid == 0) {
-        int before[kMaxOct * kMaxDog];
-        for (int k = 0; k < g.nlev; k++) before[k] = s_lc[k];
-        const int total = apply_level_limits(s_lc, g.nlev, lp, true);
-        for (int k = 0; k < g.nlev; k++) {
-          s_keep[k] = (s_lc[k] == before[k]);  // a level is either kept whole or dropped
-          if (blockIdx.x == 0) level_count[b * g.nlev + k] = s_lc[k];
-        }
-        if (blockIdx.x == 0) {
-          raw_total[b] = total < cap_raw ? total : cap_raw;
-          if (total > cap_raw) atomicMax(overflow, total);
-        }
-      }
-      __syncthreads();
-      if (limits) {
-#pragma unroll
-        for (int u = 0; u < RC; u++) cc[u] = s_keep[min(lis[u], g.nlev - 1)] ? cc[u] : 0;  // dropped rows count 0: offsets stay monotone
-      }
-    }
-    int mine = 0;
-#pragma unroll
-    for (int u = 0; u < RC; u++) mine += cc[u];
-    int inc = mine;  // inclusive scan over the 256 threads: wavefront scan + four wavefront sums
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(inc, d);
-      if (lane >= d) inc += v;
-    }
-    if (lane == 63) s_wsum[wv] = inc;
-    __syncthreads();
-    int e = inc - mine;
-    for (int k = 0; k < wv; k++) e += s_wsum[k];
-    if (tid == 0) s_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-#pragma unroll
-    for (int u = 0; u < RC; u++) {  // counts -> exclusive offsets, in place
-      if (u < per && r0 + u < r1) s_off[r0 + u] = e;
-      e += cc[u];
-    }
-    __syncthreads();
-    n = min(s_total, cap_raw);
-    off = s_off;
-  } else {
-    n = raw_total[b];
-    off = rowoff_or_cnt + (long long)b * g.NR;
-  }
-  if (i >= n) return;
-  // the detection's row is the LAST row whose exclusive offset is <= i (offsets are non-decreasing;
-  // empty rows and rows of levels dropped by -tc count 0 and so never qualify as the last one)
-  // eight-way search: the seven probes of a step are independent loads (one round trip instead of three)
-  int lo = 0, hi = g.NR - 1;  // off[lo] <= i throughout (off[0] = 0); the answer lies in [lo, hi]
-  while (hi - lo >= 8) {
-    const int step = (hi - lo) >> 3;
-    int v[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) v[k] = off[lo + step * (k + 1)];
-    int nl = lo, nh = hi;
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const int p = lo + step * (k + 1);
-      if (v[k] <= i) nl = p; else nh = min(nh, p - 1);
-    }
-    lo = nl; hi = nh;
-  }
-  {
-    int v[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) v[k] = off[min(lo + 1 + k, hi)];
-    int r = lo;
-#pragma unroll
-    for (int k = 0; k < 7; k++) if (lo + 1 + k <= hi && v[k] <= i) r = lo + 1 + k;
-    lo = r;
-  }
-  const int ri = lo;
-  int oct = 0;
-  for (int k = 1; k < g.noct; k++) if (g.o[k].row_base <= ri) oct = k;
-  const OctGeom& og = g.o[oct];
-  const int rel = ri - og.row_base;
-  const int lm1 = rel / og.h, row = rel - lm1 * og.h, l = lm1 + 1;
-  const uint64_t* mrow = rowmask + (long long)b * g.NM + og.mask_base + (lm1 * og.h + row) * og.w64;
-  int rank = i - off[ri];
-  int col = -1;
-  // the rank-th set bit of the row's mask words, eight words per trip so that their loads are in flight together
-  for (int w0 = 0; w0 < og.w64 && col < 0; w0 += 8) {
-    uint64_t mw[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) mw[k] = mrow[min(w0 + k, og.w64 - 1)];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (col < 0 && w0 + k < og.w64) {
-        uint64_t m = mw[k];
-        const int c = __popcll(m);
-        if (rank < c) {
-          for (int q = 0; q < rank; q++) m &= m - 1;  // drop the lower `rank` set bits
-          col = (w0 + k) * 64 + __builtin_ctzll(m);
-        }
-        rank -= c;
-      }
-    }
-  }
-  if (col < 0) return;  // cannot happen: counts and masks come from the same pass
-  const long long poff = og.lvl_off + ((long long)l * g.B + b) * og.plane;
-  const long long lstep = (long long)g.B * og.plane;
-  const float* C = deth + poff;
-  KeyVal kv;
-  key_eval<false>(C, C - lstep, C + lstep, gauss + poff, og.wa, row * og.wa + col, dp, &kv);
-  RawKey rk;
-  rk.level_index = oct * g.dog + lm1; rk.col = col; rk.row = row; rk.packed = kv.packed;
-  rk.dx = kv.dx; rk.dy = kv.dy; rk.ds = kv.ds; rk.pad = 0;
-  raw[(long long)b * cap_raw + i] = rk;
-  // histogram of the top-K selection key abs(half(response)), 15 bits (topk_select_kernel): counted here, where the
-  // response has just been computed, instead of by a pass of its own over the list.  SelectTopK is skipped when
-  // there are fewer than K detections (PyramidCU.cpp:1886).
-  if (hist && n >= topk) atomicAdd(&hist[(long long)b * kHistBins + ((rk.packed >> 16) & 0x7fffu)], 1u);
-}
 
 // =============================== block scan helpers ==========================================
 
@@ -799,13 +679,15 @@ __device__ int apply_level_limits(int* lc, int nlev, const LimitParams& lp, bool
   return total;
 }
 
-__global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, const int* rowcnt, int* rowoff,
-                                                        int* level_count, int* raw_total, int cap_raw,
-                                                        int* overflow) {
+// Row counts of image b -> exclusive offsets in list order (level, row), level totals, -tc level truncation
+// (GenerateFeatureList / LimitFeatureCount, PyramidCU.cpp:1283-1368, SiftPyramid.cpp:201-278), by ONE workgroup of 1024
+// threads (every thread of it calls).
+__device__ void row_scan_block(const Geom& g, const LimitParams& lp, const int* rowcnt, int* rowoff, int* level_count,
+                               int* raw_total, int cap_raw, int* overflow, int b) {
   __shared__ int lc[kMaxOct * kMaxDog];
   __shared__ int keep[kMaxOct * kMaxDog];
   __shared__ int lds[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int* cnt = rowcnt + (long long)b * g.NR;
   int* off = rowoff + (long long)b * g.NR;
   for (int i = tid; i < g.nlev; i += 1024) lc[i] = 0;
@@ -814,9 +696,9 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
   // decided which levels stay) one workgroup scan over the threads' sums and a serial walk over the own rows.
   const int per = (g.NR + 1023) >> 10;
   const int r0 = tid * per, r1 = min(g.NR, r0 + per);
-  // Up to RC rows per thread (images up to ~5000 rows per level) are read once, with independent loads, and kept in
-  // registers; the level of a row follows from walking the level boundaries, not from a division per row.
-  constexpr int RC = 16;
+  // Up to RC rows per thread (32 768 rows per image: a 4096^2 image has 24 552) are read once, with independent loads,
+  // and kept in registers; the level of a row follows from walking the level boundaries, not from a division per row.
+  constexpr int RC = 32;
   __shared__ int oct_h[kMaxOct], oct_base[kMaxOct];
   for (int i = tid; i < g.noct; i += 1024) { oct_h[i] = g.o[i].h; oct_base[i] = g.o[i].row_base; }
   __syncthreads();
@@ -930,6 +812,95 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(Geom g, LimitParams lp, 
     const int c = cnt[i];
     if (c && keep[level_of_row(i)]) e += c;
   }
+}
+
+// List order.  The unordered detections of image b -- the tasks' slots (task_count[t] of DT_SLOTS in use) and the spill
+// list -- are copied to their places in the raw list: position = exclusive offset of the detection's row in list order +
+// number of detections of that row to its left (mask bits below its column).  Workgroups take chunks of 1024 store
+// positions in ARRIVAL order (ticket); the first to arrive scans the image's row counts (row_scan_block) and raises the
+// image's flag, the others load their records and count their mask bits meanwhile and then wait for the flag -- a
+// bounded, sleeping wait on a workgroup that is running by construction (it drew its ticket first); a flag that never
+// comes ends as a device-side error word the host reports (overflow[2], as topk_select_kernel), not as a hung stream.
+// ticket / flag arrive zeroed.
+constexpr int PL_SPIN_LIMIT = 1 << 21;
+
+__global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams lp, DetectStore ds, const uint64_t* rowmask,
+                                                             const int* rowcnt, int* rowoff, int* level_count, int* raw_total,
+                                                             int* overflow, int* ticket, int* flag, RawKey* raw, int cap_raw) {
+  __shared__ int s_ck;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid == 0) s_ck = atomicAdd(&ticket[b], 1);
+  __syncthreads();
+  const int ck = s_ck;
+  const int nslot = ds.ntask * DT_SLOTS;
+  const int total = nslot + min(ds.spill_count[b], ds.cap_spill);
+  if (ck != 0 && ck * 1024 >= total) return;  // (workgroup-uniform) nothing in this chunk; nobody waits for it
+  if (ck == 0) {
+    row_scan_block(g, lp, rowcnt, rowoff, level_count, raw_total, cap_raw, overflow, b);
+    __threadfence();  // the offsets and level totals, before the flag
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&flag[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // A store position's record and the number of detections of its row to its left (mask bits below its column):
+  // independent of the scan, so the first trip's are in registers before the flag is awaited.
+  struct Pending { uint4 ra, rb; int li, ri, rank; bool valid; };
+  auto fetch = [&](int i) {
+    Pending p;
+    p.valid = i < total && !(i < nslot && (i & (DT_SLOTS - 1)) >= ds.task_count[(long long)b * ds.ntask + i / DT_SLOTS]);
+    p.ra = p.rb = make_uint4(0u, 0u, 0u, 0u);
+    p.li = p.ri = p.rank = 0;
+    if (!p.valid) return p;
+    const uint4* const src = reinterpret_cast<const uint4*>(ds.found + (long long)b * ds.stride + i);
+    p.ra = src[0]; p.rb = src[1];
+    p.li = (int)p.ra.x;
+    const int col = (int)p.ra.y, row = (int)p.ra.z;
+    const int oct = p.li / g.dog, lm1 = p.li - oct * g.dog;
+    const OctGeom& og = g.o[oct];
+    p.ri = og.row_base + lm1 * og.h + row;
+    const uint64_t* const mrow = rowmask + (long long)b * g.NM + og.mask_base + (lm1 * og.h + row) * og.w64;
+    const int wcol = col >> 6;
+    p.rank = __popcll(mrow[wcol] & ((1ull << (col & 63)) - 1ull));
+    for (int w0 = 0; w0 < wcol; w0 += 8) {  // eight loads in flight per trip
+      uint64_t mw[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) mw[k] = (w0 + k < wcol) ? mrow[w0 + k] : 0ull;
+#pragma unroll
+      for (int k = 0; k < 8; k++) p.rank += __popcll(mw[k]);
+    }
+    return p;
+  };
+  auto place = [&](const Pending& p) {
+    if (!p.valid) return;
+    // (written by another workgroup of this launch, possibly on another XCD: loads that go to the coherent level)
+    if (__hip_atomic_load(&level_count[b * g.nlev + p.li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // level dropped by a -tc rule
+    const int pos = __hip_atomic_load(&rowoff[(long long)b * g.NR + p.ri], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + p.rank;
+    if (pos < cap_raw) {
+      uint4* const dst = reinterpret_cast<uint4*>(raw + (long long)b * cap_raw + pos);
+      dst[0] = p.ra;
+      dst[1] = p.rb;
+    }
+  };
+  const Pending first = fetch(ck * 1024 + tid);
+  if (ck != 0) {
+    // ONE thread of the workgroup polls, with plain coherent loads (an ACQUIRE load per poll invalidates the cache the
+    // scanning workgroup is working from, and sixteen polling wavefronts per workgroup crowd the path the scan's own
+    // loads take: 0.29 / 0.068 ms per step in the first forms of this kernel); what is read after the flag is read with
+    // coherent loads too
+    __shared__ int s_ok;
+    if (tid == 0) {
+      int v = __hip_atomic_load(&flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; !v && spin < PL_SPIN_LIMIT; spin++) {
+        __builtin_amdgcn_s_sleep(32);
+        v = __hip_atomic_load(&flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!v) atomicMax(overflow + 2, 1);
+      s_ok = v;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+  }
+  place(first);
+  for (int i = ck * 1024 + tid + gridDim.x * 1024; i < total; i += gridDim.x * 1024) place(fetch(i));  // (a spill list that outgrows the grid: rare)
 }
 
 // =============================== top-K =======================================================
@@ -1146,24 +1117,24 @@ void launch_hessian_level(hipStream_t st, const Geom& g, const float* gauss, flo
 
 bool extrema_streams(const Geom& g) { return g.dog <= 5 && g.o[0].wa < (1 << 14) && g.o[0].h < (1 << 14); }
 
+int extrema_tasks(const Geom& g) { return extrema_streams(g) ? g.nstream * 4 : g.ntiles; }
+
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
-                         const float* deth, uint64_t* rowmask, int* rowcnt, int batch, int first_block, int nblocks) {
-  (void)gauss;
-  // rowcnt and rowmask arrive zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
-  // streaming scan (sets mask bits with atomics); its candidate queue packs row and column in 14 bits each
+                         const float* deth, uint64_t* rowmask, int* rowcnt, const DetectStore& ds, int batch) {
+  // rowcnt, rowmask, ds.spill_count and ds.hist arrive zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
+  // streaming scan; its candidate queue packs row and column in 14 bits each
   if (extrema_streams(g)) {
     unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);
-    // (first_block, nblocks): a range of the image's workgroups -- octaves back to back, g.o[].stream_base -- or all of them
-    const int b0 = first_block > 0 ? first_block : 0, nb = nblocks > 0 ? nblocks : g.nstream - b0;
-    if (nb <= 0) return;
-    const dim3 grid(nb, batch), blk(256);
+    const dim3 grid(g.nstream, batch), blk(256);
+#define HESS_STREAM_LAUNCH(D) hipLaunchKernelGGL(extrema_stream_kernel<D>, grid, blk, 0, st, g, dp, gauss, deth, rm, rowcnt, ds)
     switch (g.dog) {
-      case 1: hipLaunchKernelGGL(extrema_stream_kernel<1>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
-      case 2: hipLaunchKernelGGL(extrema_stream_kernel<2>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
-      case 3: hipLaunchKernelGGL(extrema_stream_kernel<3>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
-      case 4: hipLaunchKernelGGL(extrema_stream_kernel<4>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
-      default: hipLaunchKernelGGL(extrema_stream_kernel<5>, grid, blk, 0, st, g, dp, deth, rm, rowcnt, b0); break;
+      case 1: HESS_STREAM_LAUNCH(1); break;
+      case 2: HESS_STREAM_LAUNCH(2); break;
+      case 3: HESS_STREAM_LAUNCH(3); break;
+      case 4: HESS_STREAM_LAUNCH(4); break;
+      default: HESS_STREAM_LAUNCH(5); break;
     }
+#undef HESS_STREAM_LAUNCH
     return;
   }
   // more than 5 detection levels per octave, or planes of 16384 px and more: LDS-tiled scan (level count
@@ -1175,38 +1146,16 @@ void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_allowed = lds;
   }
-  hipLaunchKernelGGL(extrema_mark_kernel, dim3(g.ntiles, batch), dim3(256), lds, st, g, dp, deth, rowmask, rowcnt);
+  hipLaunchKernelGGL(extrema_mark_kernel, dim3(g.ntiles, batch), dim3(256), lds, st, g, dp, gauss, deth, rowmask, rowcnt, ds);
 }
 
-void launch_row_scan(hipStream_t st, const Geom& g, const LimitParams& lp, const int* rowcnt, int* rowoff,
-                     int* level_count, int* raw_total, int cap_raw, int* overflow, int batch) {
-  hipLaunchKernelGGL(row_scan_kernel, dim3(batch), dim3(1024), 0, st, g, lp, rowcnt, rowoff, level_count,
-                     raw_total, cap_raw, overflow);
-}
-
-bool extrema_scatter_scans(const Geom& g) { return g.NR <= SC_MAXROWS; }
-static int scatter_scan_policy() {  // HESS_SCATTER_SCAN: 1 = always scan in the scatter launch, 0 = never, unset = by batch size
-  static const int v = [] { const char* e = getenv("HESS_SCATTER_SCAN"); return e ? atoi(e) : -1; }();
-  return v;
-}
-
-void launch_extrema_scatter(hipStream_t st, const Geom& g, const DetectParams& dp, const LimitParams& lp, const float* gauss,
-                            const float* deth, const uint64_t* rowmask, const int* rowcnt, int* rowoff, int* level_count,
-                            int* raw_total, int* overflow, RawKey* raw, int cap_raw, int batch, unsigned* hist, int topk) {
-  const dim3 grid((cap_raw + 255) / 256, batch);
-  // One or two images: the scatter workgroups scan the row counts themselves, in LDS (a 12 us single-workgroup launch
-  // less in the image's dependent chain).  Larger batches keep row_scan_kernel: every scatter workgroup repeating the
-  // scan is 512 scans instead of 8 for a batch of eight, and six pipelined contexts lose 2 % to it (18.06 - 18.10
-  // against 18.36 - 18.53 Gpix/s, same call) -- on a saturated device the redundant work costs more than the launch.
-  const int pol = scatter_scan_policy();
-  if (extrema_scatter_scans(g) && (pol < 0 ? batch <= 2 : pol > 0)) {
-    hipLaunchKernelGGL(extrema_scatter_kernel<true>, grid, dim3(256), 0, st, g, dp, lp, gauss, deth, rowmask, rowcnt,
-                       raw_total, level_count, overflow, raw, cap_raw, hist, topk);
-    return;
-  }
-  launch_row_scan(st, g, lp, rowcnt, rowoff, level_count, raw_total, cap_raw, overflow, batch);
-  hipLaunchKernelGGL(extrema_scatter_kernel<false>, grid, dim3(256), 0, st, g, dp, lp, gauss, deth, rowmask, rowoff,
-                     raw_total, level_count, overflow, raw, cap_raw, hist, topk);
+void launch_extrema_place(hipStream_t st, const Geom& g, const LimitParams& lp, const DetectStore& ds, const uint64_t* rowmask,
+                          const int* rowcnt, int* rowoff, int* level_count, int* raw_total, int* overflow, int* ticket,
+                          int* flag, RawKey* raw, int cap_raw, int batch) {
+  // the tasks' slots + a spill list of up to 16 chunks at a time (longer spill lists take more trips: they are rare)
+  const int chunks = (ds.ntask * DT_SLOTS + std::min(ds.cap_spill, 16 * 1024) + 1023) / 1024;
+  hipLaunchKernelGGL(extrema_place_kernel, dim3(chunks, batch), dim3(1024), 0, st, g, lp, ds, rowmask, rowcnt, rowoff,
+                     level_count, raw_total, overflow, ticket, flag, raw, cap_raw);
 }
 
 int topk_chunks(int cap_raw) { return (cap_raw + TK_CHUNK - 1) / TK_CHUNK; }

@@ -18,6 +18,7 @@
 //                of its cell and adds the iteration's samples to them through a per-wavefront LDS coefficient
 //                table (see descriptor_kernel).
 // Built without the SLP vectoriser (hessgpu_amd/build.py): packed FP32 issues at half rate on gfx950.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1109,10 +1110,22 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
                        int cap_list, const FRec* recs, const int* fsrc, const int* feat_total,
                        const int* feat_first, const int* img_base, const float* got, HostKeypoint* keys,
-                       float* desc, int cap_feat, int batch) {
+                       float* desc, int cap_feat, int batch, int seen_features) {
   // (dp.first_image: first image of this launch; `batch` images from there)
-  int blocks = (cap_feat + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  // Grid: one wavefront per feature where that is known to fit -- the workgroup dispatcher then hands the features out
+  // largest first as wavefront slots free up, which a fixed stride over a smaller grid does not (configs[4], 25 k features
+  // per launch over 8192 wavefronts of which 5120 are resident: 0.549 -> 0.473 ms per image with 16384, same call,
+  // profiles/r06_experiments/descriptor_grid.txt).  The count of this batch is not known on the host; the largest count per
+  // image of the context's last batch (+ 25 %) stands in for it, and the stride loop covers what exceeds the grid.
+  // Multiples of 128 workgroups keep whole XCD blocks (see dpx.xcd_block below).
+  const int den = dp.part_den > 1 ? dp.part_den : 1;
+  int blocks = 2048;
+  if (seen_features > 0) {
+    const long long want = ((long long)seen_features * 5 / 4 / den + 3) / 4;
+    blocks = (int)std::min<long long>(16384, std::max<long long>(256, (want + 127) / 128 * 128));
+  }
+  const int cap_blocks = (cap_feat / den + 3) / 4;
+  if (blocks > cap_blocks) blocks = cap_blocks;
   if (blocks < 1) blocks = 1;
   const int lds_pad = DC_LDS_PAD_BYTES;
   DescParams dpx = dp;
