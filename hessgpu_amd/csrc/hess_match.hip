@@ -4,12 +4,14 @@
 // RowMatch_Kernel, ColMatch_Kernel (ProgramCU.cu:3455-3843).  Integer work: results are bit-exact.
 //
 // Unguided match (GetSiftMatch): matrix cores, no score matrix in memory --
-//   match_mfma_kernel      one wavefront per (32-row block, column segment): v_mfma_i32_32x32x32_i8 tiles whose
-//                          C layout (column on the lane, 16 rows in registers) makes RowMatch_Kernel's 32 strided
-//                          thread scans and the column partials per-lane folds; see the comment at the kernel;
-//   match_rowmerge_kernel  merges the per-segment thread states in column order, then the reference's 32-thread
-//                          tree (partners 16, 8, 4, 2, 1 apart, ties keep the lower thread), acos distance + ratio;
-//   match_col_kernel       merges the per-row-block (max, index, second) column partials in ascending row order.
+//   match_mfma_kernel      one workgroup per (256-row block, column segment): the segment's descriptors of set 2 pass
+//                          through LDS once for its four wavefronts, each of which holds 64 rows of set 1 in registers and
+//                          folds the v_mfma_i32_32x32x32_i8 tiles into RowMatch_Kernel's per-thread states and the column
+//                          partials as packed 32-bit keys; see the comment at the kernel;
+//   match_finish_kernel    merges a row's per-segment states (largest score, then the reference's tie order: lower
+//                          thread class, lower column), acos distance + ratio;
+//                          and, in the same launch, the per-row-block (max, index, second) column partials in ascending
+//                          row order (match_col_kernel: the same for the small / guided path).
 // Guided match (GetGuidedSiftMatch: per-pair homography / fundamental-matrix gates, per-8-row-block rule) --
 //   match_dot_kernel       64x64 tile of the dot-product matrix per workgroup, descriptor panels in LDS,
 //                          v_dot4_u32_u8, gates per pair, score matrix written for
@@ -22,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hess_abi.h"
@@ -185,11 +188,11 @@ __global__ __launch_bounds__(256) void match_row_kernel(const int* dotm, int num
 // ColMatch_Kernel (ProgramCU.cu:3808-3827): merge the row-block partials of a column in ascending row order.
 // The merge is associative (ties go to the earlier rows), so a column's partials are split into 8 consecutive
 // chunks folded by 8 threads and combined in chunk order: 32 columns x 8 chunks per workgroup.
-__global__ __launch_bounds__(256) void match_col_kernel(const int3* cpart, int ntile, int num2, float distmax,
-                                                        float ratiomax, int* colm) {
+__device__ __forceinline__ void match_col_block(int block, const int3* cpart, int ntile, int num2, float distmax,
+                                                float ratiomax, int* colm) {
   __shared__ int3 part[8][32];
   const int c = threadIdx.x & 31, ch = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + c;
+  const int j = block * 32 + c;
   const int per = (ntile + 7) >> 3;
   const int q0 = ch * per, q1 = min(q0 + per, ntile);
   int3 t = make_int3(0, -1, 0);  // neutral: the per-block partials start from the same state
@@ -211,127 +214,224 @@ __global__ __launch_bounds__(256) void match_col_kernel(const int3* cpart, int n
   }
 }
 
+__global__ __launch_bounds__(256) void match_col_kernel(const int3* cpart, int ntile, int num2, float distmax,
+                                                        float ratiomax, int* colm) {
+  match_col_block(blockIdx.x, cpart, ntile, num2, distmax, ratiomax, colm);
+}
+
 // ---- unguided match on the matrix cores -----------------------------------------------------------------
-// The num1 x num2 dot products are never written out.  One wavefront owns a block of 32 rows and a segment
-// of the columns and walks the segment in 32-column tiles: 4 x v_mfma_i32_32x32x32_i8 per tile (A fragments =
-// the block's 32 descriptors, resident in registers; B fragments = 32 descriptors of set 2, 16-byte loads
-// straight from L2, no LDS).  The C layout puts column j0 + (lane & 31) on the lane and 16 rows in its
-// registers, and a tile aligned to 32 columns holds exactly one element of each of RowMatch_Kernel's 32
-// strided threads (class = j mod 32 = lane & 31): the per-thread scan of the reference (strict '>' keeps
-// the first maximum, second = second largest) is a per-lane fold over the tiles with no cross-lane traffic.
-// Column partials (max, index, second over the block's rows in ascending order, ColMatch's merge rule) are
-// folded per lane over the registers and merged once across the two lane halves.
-// Descriptors are unsigned bytes, the instruction multiplies signed ones: bytes are biased by -128 (xor 0x80)
-// and the exact dot product is restored as dot_s + 128 (sum a + sum b) - 128^2 * 128 from per-descriptor sums.
+// The num1 x num2 dot products are never written out.
+//
+// Work split.  A workgroup (four wavefronts) owns 256 rows of set 1 and a segment of the columns (set 2); wavefront w
+// holds rows 64 w .. 64 w + 63 as the A fragments of two 32-row blocks, resident in registers.  The segment is walked
+// in SUPER TILES of 128 columns: the workgroup copies the 16 KB of descriptors (biased, see below) and the 128 column
+// offsets into LDS -- one coalesced 16-byte load per thread and quarter, issued a whole super tile ahead, double
+// buffered, one barrier per super tile -- and every wavefront reads its B fragments from there: set 2 crosses L2 once
+// per 256 rows (round 1-5's kernel: once per 32 rows, straight from L2, 16 bytes per lane at a 32-byte stride).
+// Per 32-column tile a wavefront issues 2 x 4 v_mfma_i32_32x32x32_i8.
+//
+// Scores.  Descriptors are unsigned bytes, the instruction multiplies signed ones: bytes are biased by -128 (xor 0x80)
+// and the exact dot product is dot_s + 128 (sum a + sum b) - 128^2 * 128.  The row part (rfix) rides in as the MFMA's
+// C operand, the column part (cfix) is added while the key is formed.  Both sets are padded with zero descriptors to
+// whole blocks (rows: 256, columns: 128), whose exact score is 0 -- never a maximum (the reference's scans start at 0
+// and replace on '>' only), so there is no validity test anywhere in the loop.
+//
+// Folds.  The C layout puts column j0 + (lane & 31) on the lane and 16 rows of a block in its registers, and a tile
+// aligned to 32 columns holds exactly one element of each of RowMatch_Kernel's 32 strided threads (class = j mod 32 =
+// lane & 31): the per-thread scan of the reference (strict '>' keeps the first maximum, second = second largest,
+// ProgramCU.cu:3745-3760) is a per-lane fold over the tiles with no cross-lane traffic.  State per (lane, register): two
+// packed keys, key = score << 6 | (62 - tile index in the segment): `best = max(best, key)` keeps the largest score and,
+// among equal scores, the earliest tile; `second = med3(best, key, second)` is the second largest key, whose score is the
+// second largest score counting duplicates -- three vector instructions per element (shift-add, med3, max) where
+// the (max, second, index) triple took seven.  63 in the low bits = "none yet" (a score of 0 forms a key below it).
+// Column partials (max, row, second over the wavefront's rows in ascending order, ColMatch's rule, ProgramCU.cu:3510-3519)
+// the same way with key = score << 6 | (62 - row in the lane's half), formed from the row key by one add of a scalar.
+// At the end of the segment the 32 classes of a row are merged through LDS (one lane per row walks them in ascending
+// class order: the reference's tree keeps the lower thread on ties, ProgramCU.cu:3766-3780) and ONE (best, second,
+// column) per row and segment is stored.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MM_ROWS = 256;            // rows of set 1 per workgroup (64 per wavefront)
+constexpr int MM_SUPER = 128;           // columns per super tile
+constexpr int MM_PITCH = KD + 16;       // LDS bytes per staged descriptor: 36 dwords, 16-byte reads of 32 columns spread over the banks
+constexpr int MM_MAX_TILES = 60;        // tiles per segment: the tile index shares 6 key bits with "none"
+constexpr int MM_RS_PITCH = 33;         // row-state exchange: 8-byte entries per row (32 classes + 1 pad)
 
 __device__ __forceinline__ void col_merge(int3& a, const int3& b) {  // a: earlier rows, b: later rows
   if (a.x < b.x) a = make_int3(b.x, b.y, max(a.x, b.z));
   else a.z = max(a.z, b.x);
 }
 
+// median of three (v_med3_i32: the compiler does not form it from min/max of three variables)
+__device__ __forceinline__ int med3i(int a, int b, int c) {
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <bool COLS>
 __global__ __launch_bounds__(256) void match_mfma_kernel(const uint8_t* des1, int num1, const uint8_t* des2, int num2,
-                                                         const int* rfix, const int* cfix, int nseg, int tiles_per_seg,
-                                                         int3* cpart, int3* rstate) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                                                         const int* rfix, const int* cfix, int nseg, int supers_per_seg,
+                                                         int nsuper, int3* cpart, int3* rstate) {
+  __shared__ __attribute__((aligned(16))) uint8_t bufB[2][MM_SUPER * MM_PITCH];
+  __shared__ int bufC[2][MM_SUPER];
+  __shared__ int3 cp[2][4][MM_SUPER];  // the four wavefronts' column partials of a super tile, merged after its barrier
+  static_assert(sizeof(bufB) >= 4 * 32 * MM_RS_PITCH * 8, "the row-state exchange reuses the descriptor buffers");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int rb = blockIdx.x, sg = blockIdx.y * 4 + wv;
-  if (sg >= nseg) return;  // wavefront-uniform; no workgroup barrier in this kernel
-  const int i0 = rb * 32;
-  const int ntile2 = (num2 + 31) >> 5;
-  v4i a[4];
+  const int sg = blockIdx.y;
+  const int i0 = blockIdx.x * MM_ROWS + wv * 64;  // this wavefront's first row
+  const int s0 = sg * supers_per_seg, s1 = min(s0 + supers_per_seg, nsuper);
+  v4i a[2][4];
+  v16i ra[2];
   {
-    // hardware row r of the tile carries descriptor row i0 + perm(r), chosen so that the 16 accumulator
-    // registers of a lane are 16 CONSECUTIVE descriptor rows (i0 + reg + 16 h): the column partial of a
-    // lane is then a plain in-order fold and the two lane halves merge once per tile
+    // hardware row r of a tile carries descriptor row perm(r) of the block, chosen so that the 16 accumulator registers
+    // of a lane are 16 CONSECUTIVE descriptor rows (reg + 16 h): a lane's column partial is then a plain in-order fold
     const int prow = (r & 3) + 4 * (r >> 3) + 16 * ((r >> 2) & 1);
-    const uint8_t* pa = des1 + (size_t)min(i0 + prow, num1 - 1) * KD + 16 * h;
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) a[kk] = *reinterpret_cast<const v4i*>(pa + kk * 32) ^ (int)0x80808080;
+    for (int blk = 0; blk < 2; blk++) {
+      const uint8_t* pa = des1 + (size_t)(i0 + 32 * blk + prow) * KD + 16 * h;  // (set 1 is padded to whole workgroups)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) a[blk][kk] = *reinterpret_cast<const v4i*>(pa + kk * 32) ^ (int)0x80808080;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) ra[blk][reg] = rfix[i0 + 32 * blk + reg + 16 * h];
+    }
   }
-  int ra[16], mx[16], nx[16], ix[16];
+  int rmx[2][16], rnx[2][16];
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int row = i0 + reg + 16 * h;
-    ra[reg] = row < num1 ? rfix[row] : -(1 << 29);  // rows past the end: far below every real score, no overflow
-    mx[reg] = 0; nx[reg] = 0; ix[reg] = -1;          // RowMatch_Kernel's initial state, ProgramCU.cu:3745-3747
-  }
-  const int t1 = min((sg + 1) * tiles_per_seg, ntile2);
-  auto load_b = [&](int t, v4i (&b)[4], int& cbv) {  // B fragments + column offset of tile t (clamped past the end)
-    const int jj = t * 32 + r;
-    const int jc = min(jj, num2 - 1);
-    const uint8_t* pb = des2 + (size_t)jc * KD + 16 * h;
+  for (int blk = 0; blk < 2; blk++)
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) b[kk] = *reinterpret_cast<const v4i*>(pb + kk * 32);
-    cbv = jj < num2 ? cfix[jc] : -(1 << 29);  // columns past the end: far below every real score
+    for (int reg = 0; reg < 16; reg++) { rmx[blk][reg] = 63; rnx[blk][reg] = 0; }
+
+  // staging: thread t copies 16-byte pieces t, t + 256, t + 512, t + 768 of a super tile (piece = 8 x column + part)
+  v4i st[4];
+  int stc = 0;
+  auto stage_load = [&](int sup) {
+    const uint8_t* src = des2 + (size_t)sup * MM_SUPER * KD + (size_t)tid * 16;
+#pragma unroll
+    for (int q = 0; q < 4; q++) st[q] = *reinterpret_cast<const v4i*>(src + q * 4096);
+    if (tid < MM_SUPER) stc = cfix[sup * MM_SUPER + tid];
   };
-  v4i bn[4];
-  int cbn;
-  load_b(sg * tiles_per_seg, bn, cbn);
-  for (int t = sg * tiles_per_seg; t < t1; t++) {
-    const int j = t * 32 + r;
-    v4i b[4];
+  auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) b[kk] = bn[kk] ^ (int)0x80808080;
-    const int cb = cbn;
-    load_b(min(t + 1, ntile2 - 1), bn, cbn);  // next tile's loads fly while this tile is reduced
-    v16i c = {0};
+    for (int q = 0; q < 4; q++) {
+      const int piece = tid + 256 * q;
+      *reinterpret_cast<v4i*>(&bufB[buf][(piece >> 3) * MM_PITCH + (piece & 7) * 16]) = st[q] ^ (int)0x80808080;
+    }
+    if (tid < MM_SUPER) bufC[buf][tid] = stc;
+  };
+  stage_load(s0);
+  stage_store(0);
+  __syncthreads();
+  for (int sup = s0; sup < s1; sup++) {
+    const int cur = (sup - s0) & 1;
+    if (sup + 1 < s1) stage_load(sup + 1);  // in flight while this super tile is multiplied
+    // (one tile at a time: a software pipeline over the tiles -- the next tile's MFMAs issued between this tile's folds --
+    // needs 260 registers, spills at two wavefronts per SIMD and runs 9 % slower: profiles/r06_experiments/matcher.txt)
+#pragma unroll 1
+    for (int tt = 0; tt < 4; tt++) {
+      const int tl = (sup - s0) * 4 + tt;     // tile index in the segment
+      const int ct = 62 - tl;
+      const uint8_t* pb = &bufB[cur][(tt * 32 + r) * MM_PITCH + 16 * h];
+      v4i b[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk], b[kk], c, 0, 0, 0);
-    int cx = 0, cy = -1, cz = 0;  // column partial over this lane's 16 rows (ProgramCU.cu:3510-3519)
+      for (int kk = 0; kk < 4; kk++) b[kk] = *reinterpret_cast<const v4i*>(pb + kk * 32);
+      const int cbk = (bufC[cur][tt * 32 + r] << 6) | ct;
+      int cx = 63, cz = 0;  // column partial over this lane's 32 rows
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      const int v = c[reg] + ra[reg] + cb;                     // invalid row/column: far below 0
-      // RowMatch_Kernel's thread update (ProgramCU.cu:3756-3760); second = median(max, v, second)
-      nx[reg] = max(min(mx[reg], v), nx[reg]);
-      ix[reg] = (v > mx[reg]) ? j : ix[reg];
-      mx[reg] = max(mx[reg], v);
-      if (cpart) {
-        cz = max(min(cx, v), cz);
-        cy = (v > cx) ? i0 + reg + 16 * h : cy;
-        cx = max(cx, v);
+      for (int blk = 0; blk < 2; blk++) {
+        v16i c = ra[blk];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[blk][kk], b[kk], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+          const int k = (int)(((unsigned)c[reg] << 6) + (unsigned)cbk);  // (score << 6) | ct: score = c + column offset >= 0
+          rnx[blk][reg] = med3i(rmx[blk][reg], k, rnx[blk][reg]);
+          rmx[blk][reg] = max(rmx[blk][reg], k);
+          if (COLS) {
+            const int kc = k + ((62 - (reg + 16 * blk)) - ct);            // low bits: 62 - row in the lane's half
+            cz = med3i(cx, kc, cz);
+            cx = max(cx, kc);
+          }
+        }
+      }
+      if (COLS) {
+        // the lane's rows are (reg, 32 + reg) + 16 h of the wavefront's 64: decode, then merge the two lane halves
+        // (largest score; equal scores: the lower row, ColMatch's ascending order)
+        const int low = cx & 63, rl = 62 - low;
+        int bx = cx >> 6, by = low == 63 ? -1 : i0 + 32 * (rl >> 4) + (rl & 15) + 16 * h, bz = cz >> 6;
+        const int ox = __shfl_xor(bx, 32), oy = __shfl_xor(by, 32), oz = __shfl_xor(bz, 32);
+        const bool take = ox > bx || (ox == bx && oy >= 0 && (by < 0 || oy < by));
+        const int nz = max(max(bz, oz), min(bx, ox));
+        bx = take ? ox : bx;
+        by = take ? oy : by;
+        if (h == 0) cp[cur][wv][tt * 32 + r] = make_int3(bx, by, nz);
       }
     }
-    if (cpart) {  // rows of lane half 0 precede those of half 1
-      const int ox = __shfl_xor(cx, 32), oy = __shfl_xor(cy, 32), oz = __shfl_xor(cz, 32);
-      int3 lo = h ? make_int3(ox, oy, oz) : make_int3(cx, cy, cz);
-      const int3 hi = h ? make_int3(cx, cy, cz) : make_int3(ox, oy, oz);
-      col_merge(lo, hi);
-      if (h == 0 && j < num2) cpart[(size_t)rb * num2 + j] = lo;
+    if (sup + 1 < s1) stage_store(cur ^ 1);  // (read last during super tile sup - 1: every wavefront is past that barrier)
+    __syncthreads();
+    if (COLS && tid < MM_SUPER) {
+      // one partial per column and WORKGROUP (256 rows): the wavefronts' partials in row order (ColMatch's merge rule);
+      // cp[cur] is next written during super tile sup + 2, i.e. after the barrier that ends sup + 1
+      int3 t = cp[cur][0][tid];
+#pragma unroll
+      for (int w = 1; w < 4; w++) col_merge(t, cp[cur][w][tid]);
+      const int j = sup * MM_SUPER + tid;
+      if (j < num2) cpart[(size_t)blockIdx.x * num2 + j] = t;
     }
   }
+  // ---- the 32 classes of every row -> one state per row and segment, through LDS (the descriptor buffers are free) ----
+  int2* const rs = reinterpret_cast<int2*>(&bufB[0][0]) + wv * 32 * MM_RS_PITCH;
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int row = i0 + reg + 16 * h;
-    if (row < num1) rstate[((size_t)row * nseg + sg) * 32 + r] = make_int3(mx[reg], nx[reg], ix[reg]);
+  for (int blk = 0; blk < 2; blk++) {
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) rs[(reg + 16 * h) * MM_RS_PITCH + r] = make_int2(rmx[blk][reg], rnx[blk][reg]);
+    __builtin_amdgcn_wave_barrier();  // (one wavefront's LDS operations complete in order)
+    if (lane < 32) {
+      const int2* const row = rs + lane * MM_RS_PITCH;
+      int2 s = row[0];
+      int cls = 0;
+#pragma unroll 8
+      for (int c2 = 1; c2 < 32; c2++) {  // ascending class order, '>' on the score: the lower class keeps a tie
+        const int2 u = row[c2];
+        const bool take = (u.x >> 6) > (s.x >> 6);
+        s.y = take ? max(s.x, u.y) : max(s.y, u.x);
+        s.x = take ? u.x : s.x;
+        cls = take ? c2 : cls;
+      }
+      const int low = s.x & 63;
+      const int grow = i0 + 32 * blk + lane;
+      if (grow < num1)
+        rstate[(size_t)grow * nseg + sg] = make_int3(s.x >> 6, s.y >> 6, low == 63 ? -1 : (s0 * 4 + 62 - low) * 32 + cls);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// Rows: merge the per-segment thread states of each of the 32 strided threads in column order (a later
-// segment only wins with a strictly larger maximum), then the reference's tree over the 32 threads.
-__global__ __launch_bounds__(256) void match_rowmerge_kernel(const int3* rstate, int num1, int nseg, float distmax,
-                                                             float ratiomax, int* rowm) {
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
-  const int rowc = min(row, num1 - 1);  // keep every lane in the shuffles below
-  const int3* p = rstate + (size_t)rowc * nseg * 32 + t;
+// Rows: merge the per-segment states in the reference's order -- largest score; equal scores: the lower thread class
+// (column mod 32: the tree keeps the lower thread), then the lower column (a thread keeps its first maximum).
+// ... and, in the same launch, the columns (match_col_block) -- workgroups [0, row_blocks) take rows, the rest columns
+// (a launch of its own for either costs more than its work: 5 us each at 8192 x 8192).
+__global__ __launch_bounds__(256) void match_finish_kernel(const int3* rstate, int num1, int nseg, int row_blocks,
+                                                           const int3* cpart, int ntile, int num2, float distmax,
+                                                           float ratiomax, int* rowm, int* colm) {
+  if ((int)blockIdx.x >= row_blocks) {  // (workgroup-uniform)
+    match_col_block(blockIdx.x - row_blocks, cpart, ntile, num2, distmax, ratiomax, colm);
+    return;
+  }
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= num1) return;
+  const int3* p = rstate + (size_t)row * nseg;
   int3 s = p[0];
   for (int q = 1; q < nseg; q++) {
-    const int3 u = p[(size_t)q * 32];
-    if (u.x > s.x) s = make_int3(u.x, max(s.x, u.y), u.z);
-    else s.y = max(s.y, u.x);
+    const int3 u = p[q];
+    const bool take = u.x > s.x || (u.x == s.x && u.z >= 0 &&
+                                    (s.z < 0 || (u.z & 31) < (s.z & 31) || ((u.z & 31) == (s.z & 31) && u.z < s.z)));
+    s.y = u.x > s.x ? max(s.x, u.y) : max(s.y, u.x);
+    if (take) { s.x = u.x; s.z = u.z; }
   }
-  int mx = s.x, nx = s.y, ix = s.z;
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) {  // ProgramCU.cu:3766-3780: partner d away, a tie keeps the lower thread
-    const int omx = __shfl_down(mx, d, 32), onx = __shfl_down(nx, d, 32), oix = __shfl_down(ix, d, 32);
-    const bool take = omx > mx;
-    const int nnx = take ? max(mx, onx) : max(nx, omx);
-    ix = take ? oix : ix;
-    mx = take ? omx : mx;
-    nx = nnx;
-  }
-  if (t == 0 && row < num1) rowm[row] = decide(mx, nx, ix, distmax, ratiomax);
+  rowm[row] = decide(s.x, s.y, s.z, distmax, ratiomax);
 }
 
 }  // namespace
@@ -417,17 +517,22 @@ int hess_matcher_set_descriptors(hess_matcher* m, int index, int num, const unsi
   (void)hipFree(m->fix[index]);
   m->fix[index] = nullptr;
   if (num) {
-    M_TRY(m, hipMalloc(&m->des[index], (size_t)num * KD));
+    // padded with zero descriptors to whole blocks of the matrix-core path (256 rows / 128 columns, match_mfma_kernel):
+    // their exact score is 0, which is never a maximum
+    const size_t padded = ((size_t)num + MM_ROWS - 1) / MM_ROWS * MM_ROWS;
+    M_TRY(m, hipMalloc(&m->des[index], padded * KD));
     M_TRY(m, hipMemcpy(m->des[index], des, (size_t)num * KD, hipMemcpyHostToDevice));
+    if (padded > (size_t)num) M_TRY(m, hipMemset(m->des[index] + (size_t)num * KD, 0, (padded - num) * KD));
     // score offsets of the matrix-core path: rows 128*sum - 128^2*128, columns 128*sum (see match_mfma_kernel)
-    std::vector<int> f((size_t)num);
-    for (int i = 0; i < num; i++) {
+    std::vector<int> f(padded);
+    for (size_t i = 0; i < padded; i++) {
       int sum = 0;
-      for (int k = 0; k < KD; k++) sum += des[(size_t)i * KD + k];
+      if (i < (size_t)num)
+        for (int k = 0; k < KD; k++) sum += des[i * KD + k];
       f[i] = 128 * sum - (index == 0 ? 128 * 128 * KD : 0);
     }
-    M_TRY(m, hipMalloc(&m->fix[index], (size_t)num * sizeof(int)));
-    M_TRY(m, hipMemcpy(m->fix[index], f.data(), (size_t)num * sizeof(int), hipMemcpyHostToDevice));
+    M_TRY(m, hipMalloc(&m->fix[index], padded * sizeof(int)));
+    M_TRY(m, hipMemcpy(m->fix[index], f.data(), padded * sizeof(int), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -477,14 +582,20 @@ int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* 
   }
   // small problems (three launches of latency) stay on the one-pass dot kernel: 1024 x 1024 0.026 vs 0.033 ms
   if (!guided && (size_t)n1 * n2 > ((size_t)3 << 20)) {
-    // matrix-core path: enough (row block, column segment) wavefronts to fill the chip
-    const int nrb = (n1 + 31) / 32, ntile2 = (n2 + 31) / 32;
-    static const int target_waves = getenv("HESS_MATCH_WAVES") ? atoi(getenv("HESS_MATCH_WAVES")) : 2048;
-    int nseg = (target_waves + nrb - 1) / nrb;
-    nseg = nseg < 1 ? 1 : (nseg > ntile2 ? ntile2 : nseg);
-    const int tiles_per_seg = (ntile2 + nseg - 1) / nseg;
-    nseg = (ntile2 + tiles_per_seg - 1) / tiles_per_seg;
-    const size_t need_rs = (size_t)n1 * nseg * 32, need_cp = (size_t)nrb * n2;
+    // matrix-core path: (256-row block, column segment) workgroups, at least two per CU where the problem allows;
+    // a segment is whole super tiles of 128 columns, at most 15 of them (the tile index shares six key bits)
+    const int nrb = (n1 + MM_ROWS - 1) / MM_ROWS, nsuper = (n2 + MM_SUPER - 1) / MM_SUPER;
+    // Workgroups: whole rounds over the 256 CUs -- two per CU (what the registers allow) when that leaves a workgroup at
+    // least four super tiles, else one per CU with twice the tiles (its prologue and the merge of the row states at its
+    // end cost about as much as two super tiles).  Same call, 4096^2 / 8192^2, TMAC/s: 256 workgroups 91 / 193, 384:
+    // 91 / 176, 512: 81 / 211, 768: 81 / 180 (profiles/r06_experiments/matcher.txt).
+    const int target_wgs = (long long)nrb * nsuper >= 512 * 4 ? 512 : 256;
+    int nseg = (target_wgs + nrb - 1) / nrb;
+    nseg = nseg < 1 ? 1 : (nseg > nsuper ? nsuper : nseg);
+    int sps = (nsuper + nseg - 1) / nseg;
+    if (sps > MM_MAX_TILES / 4) sps = MM_MAX_TILES / 4;
+    nseg = (nsuper + sps - 1) / sps;
+    const size_t need_rs = (size_t)n1 * nseg, need_cp = (size_t)nrb * n2;  // column partials per 256-row workgroup
     if (need_rs > m->rstate_cap) {
       (void)hipFree(m->rstate); m->rstate = nullptr;
       M_TRY(m, hipMalloc(&m->rstate, need_rs * sizeof(int3)));
@@ -496,13 +607,17 @@ int hess_matcher_match(hess_matcher* m, int max_match, int* pairs, const float* 
       m->cpart2_cap = need_cp;
     }
     (void)hipEventRecord(m->e0, m->st);
-    hipLaunchKernelGGL(match_mfma_kernel, dim3(nrb, (nseg + 3) / 4), dim3(256), 0, m->st, m->des[0], n1, m->des[1], n2,
-                       m->fix[0], m->fix[1], nseg, tiles_per_seg, mutual_best ? m->cpart2 : nullptr, m->rstate);
-    hipLaunchKernelGGL(match_rowmerge_kernel, dim3((n1 + 7) / 8), dim3(256), 0, m->st, m->rstate, n1, nseg, distmax,
-                       ratiomax, m->rowm);
     if (mutual_best)
-      hipLaunchKernelGGL(match_col_kernel, dim3((n2 + 31) / 32), dim3(256), 0, m->st, m->cpart2, nrb, n2, distmax,
-                         ratiomax, m->colm);
+      hipLaunchKernelGGL(match_mfma_kernel<true>, dim3(nrb, nseg), dim3(256), 0, m->st, m->des[0], n1, m->des[1], n2, m->fix[0],
+                         m->fix[1], nseg, sps, nsuper, m->cpart2, m->rstate);
+    else
+      hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(nrb, nseg), dim3(256), 0, m->st, m->des[0], n1, m->des[1], n2, m->fix[0],
+                         m->fix[1], nseg, sps, nsuper, nullptr, m->rstate);
+    // rows and -- for mutual best -- columns in one launch (the partials of row blocks past num1 hold the neutral
+    // (0, -1, 0) of their zero rows)
+    const int row_blocks = (n1 + 255) / 256;
+    hipLaunchKernelGGL(match_finish_kernel, dim3(row_blocks + (mutual_best ? (n2 + 31) / 32 : 0)), dim3(256), 0, m->st, m->rstate,
+                       n1, nseg, row_blocks, m->cpart2, nrb, n2, distmax, ratiomax, m->rowm, m->colm);
   } else {
   const size_t need = (size_t)n1 * n2;
   if (need > m->mat_cap) {

@@ -16,7 +16,10 @@ from hessgpu_amd.matcher import Matcher
 
 def main():
     rng = np.random.RandomState(0)
-    for n in (1024, 4096, 8192):
+    sizes = (1024, 4096, 8192)
+    if "--only" in sys.argv:
+        sizes = (int(sys.argv[sys.argv.index("--only") + 1]),)
+    for n in sizes:
         d1 = (rng.rand(n, 128) * 45).astype(np.uint8)
         d2 = (rng.rand(n, 128) * 45).astype(np.uint8)
         m = Matcher(0, max_sift=n)
