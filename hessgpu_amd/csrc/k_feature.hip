@@ -87,6 +87,17 @@ struct FeatScan {
   int* host_small;
 };
 
+// Inclusive prefix sum over the 64 lanes by DPP row shifts and row broadcasts (no LDS round trips).
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
+}
+
 __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan& fs, const RawKey* list, const int* list_total,
                                                    int cap_list, const int* ocount, int b, int nimg) {
   const LimitParams& lp = fs.lp;
@@ -102,42 +113,61 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
   for (int i = tid; i < g.nlev; i += NTH) lc[i] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
-  // A thread takes up to 16 consecutive keypoints per pass (their counts and levels read with independent loads),
-  // so a list of 16 k keypoints is one pass with one workgroup scan.
+  // A pass covers NTH * FC keypoints (16 384 with 1024 threads): wavefront w takes the 64 * FC consecutive keypoints
+  // [w * 64 * FC, ...) of the pass in FC steps of 64 -- lane = keypoint, so every load and store of a step is coalesced
+  // (the first form gave a THREAD 16 consecutive keypoints: its stores of a step went to 64 different cache lines, and its
+  // per-keypoint LDS atomics on the few level totals serialised lane by lane: 0.159 ms for the 65 536 keypoints of a 4096^2
+  // image on the one CU this workgroup runs on).  Counts are scanned inside the wavefront (DPP), the wavefronts' totals
+  // through LDS, and the level totals take one LDS atomic per step unless the step straddles a level boundary.
   constexpr int FC = 16;
+  const int lane = tid & 63, wv = tid >> 6, nwv = NTH >> 6;
   for (int base = 0; base < n; base += NTH * FC) {
-    const int left = n - base;
-    const int per = left >= NTH * FC ? FC : (left + NTH - 1) / NTH;  // uniform over the workgroup
-    const int i0 = base + tid * per;
-    int cc[FC], lv[FC], mine = 0;
+    const int npass = min(n - base, NTH * FC);
+    const int fc = (npass + NTH - 1) / NTH;  // steps per wavefront in this pass (a short list is spread over all wavefronts)
+    int cc[FC], ex[FC], tot[FC], wsum = 0;
 #pragma unroll
     for (int u = 0; u < FC; u++) {
-      const bool in = u < per && i0 + u < n;
-      const long long at = (long long)b * cap_list + (in ? i0 + u : 0);
+      const int k = (wv * fc + u) * 64 + lane;
+      const bool in = u < fc && k < npass;
+      const long long at = (long long)b * cap_list + base + (in ? k : 0);
       cc[u] = in ? (multi ? ocount[at] : 1) : 0;
-      lv[u] = list[at].level_index;
-    }
-#pragma unroll
-    for (int u = 0; u < FC; u++) {
-      if (cc[u]) atomicAdd(&lc[lv[u]], cc[u]);
-      mine += cc[u];
-    }
-    int tot;
-    int e = block_scan1(mine, &tot, lds);
-    const int cb = carry;
-#pragma unroll
-    for (int u = 0; u < FC; u++) {
-      if (u < per && i0 + u < n) {
-        foffset[(long long)b * cap_list + i0 + u] = cb + e;
-        // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
-        // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
-        for (int k = 0; k < cc[u]; k++)
-          if (cb + e + k < cap_feat) fsrc[(long long)b * cap_feat + cb + e + k] = (i0 + u) * 4 + k;
-        e += cc[u];
+      const int lv = in ? list[at].level_index : 0;
+      const int inc = wave_inclusive_scan(cc[u]);
+      ex[u] = inc - cc[u];
+      tot[u] = __builtin_amdgcn_readlane(inc, 63);
+      wsum += tot[u];
+      if (tot[u]) {  // (wavefront-uniform)
+        const int lv0 = __builtin_amdgcn_readfirstlane(lv);
+        if (__builtin_amdgcn_ballot_w64(cc[u] != 0 && lv != lv0) == 0) {
+          if (lane == 0) atomicAdd(&lc[lv0], tot[u]);
+        } else if (cc[u]) {
+          atomicAdd(&lc[lv], cc[u]);
+        }
       }
     }
+    if (lane == 0) lds[wv] = wsum;
     __syncthreads();
-    if (tid == 0) carry = cb + tot;
+    int run = carry, ptot = 0;
+    for (int w = 0; w < nwv; w++) {
+      const int t = lds[w];
+      run += w < wv ? t : 0;
+      ptot += t;
+    }
+#pragma unroll
+    for (int u = 0; u < FC; u++) {
+      const int k = (wv * fc + u) * 64 + lane;
+      if (u < fc && k < npass) {
+        const int off = run + ex[u];
+        foffset[(long long)b * cap_list + base + k] = off;
+        // feature m -> (keypoint i, orientation rank k): lets the descriptor stage give every
+        // wavefront real work (ReshapeFeatureListCPU's expansion, PyramidCU.cpp:780-796)
+        for (int q = 0; q < cc[u]; q++)
+          if (off + q < cap_feat) fsrc[(long long)b * cap_feat + off + q] = (base + k) * 4 + q;
+      }
+      run += tot[u];
+    }
+    __syncthreads();
+    if (tid == 0) carry += ptot;
     __syncthreads();
   }
   if (tid == 0) {
@@ -204,17 +234,6 @@ __device__ __forceinline__ float dm_expf_inrange(float x) {
   return __builtin_amdgcn_ldexpf(p, (int)n);
 }
 
-
-// Inclusive prefix sum over the 64 lanes by DPP row shifts and row broadcasts (no LDS round trips).
-__device__ __forceinline__ int wave_inclusive_scan(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
-  return v;
-}
 
 __global__ __launch_bounds__(256) void orientation_kernel(Geom g, OrientParams op, const RawKey* list,
                                                           const int* list_total, int cap_list, const float* got,
