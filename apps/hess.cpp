@@ -5,7 +5,9 @@
 // For every image: RunSIFT(index), write <image>.sift (text unless -b / -bvlf); with -time write
 // <image>.timings (11 comma-separated stage times in ms, the order of hessgpucmd.cpp:246-300) and
 // silence stdout; with -speed repeat each image 10 times and report averages (load and allocation
-// counted once).  Images are PGM/PPM (this build has no DevIL).
+// counted once).  Images: PGM / PPM built in, PNG and JPEG through libpng16 / libjpeg looked up at run time (this build
+// has no DevIL).  The files of the next list entries are decoded on host threads while an image runs
+// (hessgpu_amd/csrc/siftgpu_api.cpp, decode_ahead).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -103,7 +103,7 @@ def build_all(force=False, verbose=False):
         api_hdr = os.path.join(HERE, "..", "include", "SiftGPU.h")
         if force or _newer([api_src, api_hdr] + headers, api) or jobs:
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include")] + _jpeg_flags() +
-                 [api_src, "-o", api, "-L", HERE, "-lhessgpu", "-ldl", "-Wl,-rpath,$ORIGIN"])
+                 [api_src, "-o", api, "-L", HERE, "-lhessgpu", "-ldl", "-pthread", "-Wl,-rpath,$ORIGIN"])
         built.append(api)
         apps_dir = os.path.join(HERE, "..", "apps")
         bindir = os.path.join(HERE, "bin")

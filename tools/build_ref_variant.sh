@@ -8,6 +8,6 @@ W=/tmp/hess_wt_$N
 rm -rf $W; git -C $R worktree prune; git -C $R worktree add -f --detach $W $C > /dev/null
 (cd $W && python -m hessgpu_amd.build > /dev/null)
 mkdir -p $R/tools/_variants/$N
-cp $W/hessgpu_amd/libhessgpu.so $R/tools/_variants/$N/libhessgpu.so
+cp $W/hessgpu_amd/libhessgpu.so $W/hessgpu_amd/libsiftgpu.so $R/tools/_variants/$N/
 git -C $R worktree remove --force $W
 echo "built $N from $(git -C $R rev-parse --short $C)"
