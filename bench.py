@@ -324,7 +324,7 @@ def main():
         torch.cuda.synchronize()
 
     # Every context has run a batch before the timed region, whatever --warmup says: hess_reserve's dry batch (a context's
-    # first batch takes twice its steady time, hess_pipeline.hip prime()) and one real batch each here -- set-up, like the
+    # first batch takes twice its steady time, hess_abi.hip prime()) and one real batch each here -- set-up, like the
     # reservation itself (round 4's driver run had two of seven contexts run their FIRST batch inside the 20 timed steps).
     if not use_dist or gather_dest != "shm":   # (the shm destination has run one batch per context already, see above)
         for c in ctxs:
@@ -793,15 +793,15 @@ def _valu_entry(rate, insts, unit_key, source):
 
 
 def _mirror_is_default(batch, result_bytes=None):
-    """Whether a batch of this size is delivered by the descriptor kernel's own host stores (hess_pipeline.hip,
-    choose_delivery): HESS_DELIVERY overrides, else batches up to HESS_MIRROR_MAX_BATCH (2) whose results (keypoints +
-    descriptors of the context's batch before) stay within HESS_MIRROR_MAX_MB (16)."""
+    """Whether a batch of this size is delivered by the descriptor kernel's own host stores (hess_copier.hip,
+    choose_delivery): HESS_DELIVERY overrides, else batches up to two images whose results (keypoints + descriptors of
+    the context's batch before) stay within 16 MB."""
     pref = os.environ.get("HESS_DELIVERY")
     if pref in ("mirror", "dma", "blit"):
         return pref == "mirror"
     if result_bytes is None:
         result_bytes = batch * 6000 * (24 + 128 * 4)   # the bench workload: about 5.6 k features per image, 128-d
-    return batch <= int(os.environ.get("HESS_MIRROR_MAX_BATCH", "2")) and result_bytes <= (int(os.environ.get("HESS_MIRROR_MAX_MB", "16")) << 20)
+    return batch <= 2 and result_bytes <= (16 << 20)
 
 
 def _desc_kernel_name(order, mirror):

@@ -130,6 +130,7 @@ PRODUCT_PROTOTYPES = {
     "last_input": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "share_results": (C.c_int, [_ctx, C.c_char_p]),
     "shared_results_info": (C.c_int, [_ctx, _P(C.c_uint), _P(C.c_uint), _P(C.c_size_t), _P(C.c_size_t)]),
+    "dev_switches": (C.c_int, []),
 }
 
 

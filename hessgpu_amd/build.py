@@ -2,6 +2,7 @@
 
   hessgpu_amd/libhessgpu.so   HIP kernels + the C ABI of include/hess_abi.h
   hessgpu_amd/libsiftgpu.so   SiftGPU C++ plugin surface on top of the C ABI (if its source exists)
+  hessgpu_amd/dev/libhessgpu.so   the developer build (-DHESS_DEV_SWITCHES): same kernels, environment switches compiled in
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off: every fused multiply-add in the kernels
 is an explicit fmaf() (see csrc/hess_devmath.h).
@@ -20,9 +21,13 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-Wno-unused-function", f"--offload-arch={ARCH}"] + os.environ.get("HESS_EXTRA_FLAGS", "").split()
 
 # ROCr itself, beside the HIP runtime: the copier thread hands its device->host copies straight to an SDMA engine
-# (hsa_amd_memory_async_copy_on_engine, csrc/hess_pipeline.hip)
-LINK_LIBS = ["-lhsa-runtime64", "-lrt"]
-KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_pipeline.hip", "hess_match.hip"]
+# (hsa_amd_memory_async_copy_on_engine, csrc/hess_copier.hip)
+# -Bsymbolic: the library's own references to its functions bind inside it.  The product and the developer build are
+# loaded side by side by the tests; without it the second one's internal calls would resolve to the first one's code.
+LINK_LIBS = ["-lhsa-runtime64", "-lrt", "-Wl,-Bsymbolic"]
+KERNEL_SOURCES = ["k_gauss.hip", "k_detect.hip", "k_feature.hip", "hess_plan.hip", "hess_schedule.hip", "hess_copier.hip",
+                  "hess_shared.hip", "hess_abi.hip", "hess_match.hip"]
+DEV_SWITCH_SOURCES = ("hess_abi.hip", "hess_copier.hip", "hess_shared.hip")  # the files that call dev_env()
 # Per-file flags.  k_feature.hip: the SLP vectoriser turns pairs of FP32 operations into packed
 # instructions (v_pk_add/mul/fma_f32), which on gfx950 issue at half rate (tools/micro/README.md) and need
 # extra register moves to form the pairs: without it the descriptor kernel runs 10 % faster (1.37 -> 1.23 ms
@@ -97,6 +102,27 @@ def build_all(force=False, verbose=False):
     if force or jobs or not os.path.exists(lib):
         _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + LINK_LIBS)
     built = [lib]
+    # The developer build of the same sources: hessgpu_amd/dev/libhessgpu.so with -DHESS_DEV_SWITCHES (csrc/hess_ctx.h:
+    # schedule A/B switches, fault injection and the other test hooks read from the environment).  Only the files that
+    # read a switch are compiled again; the kernels are the product's objects.
+    dev_dir = os.path.join(HERE, "dev")
+    os.makedirs(dev_dir, exist_ok=True)
+    dev_objs, dev_jobs = [], []
+    for src, o in zip(KERNEL_SOURCES, objs):
+        if src in DEV_SWITCH_SOURCES:
+            s = os.path.join(CSRC, src)
+            od = os.path.join(OBJ, src + ".dev.o")
+            dev_objs.append(od)
+            if force or _newer([s] + headers, od):
+                dev_jobs.append([HIPCC] + CXXFLAGS + FILE_FLAGS.get(src, []) + ["-DHESS_DEV_SWITCHES", "-c", s, "-o", od])
+        else:
+            dev_objs.append(o)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(_run, dev_jobs))
+    dev_lib = os.path.join(dev_dir, "libhessgpu.so")
+    if force or jobs or dev_jobs or not os.path.exists(dev_lib):
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", dev_lib] + dev_objs + LINK_LIBS)
+    built.append(dev_lib)
     api_src = os.path.join(CSRC, "siftgpu_api.cpp")
     if os.path.exists(api_src):
         api = os.path.join(HERE, "libsiftgpu.so")

@@ -234,7 +234,7 @@ class HostLanding:
     destination's own block is already there, delivered by its context).
 
     The copy is issued on a stream of its own after the host has waited for the receives, i.e. with no stream-order
-    dependency on a kernel: the runtime then uses the DMA engine instead of a blit kernel (hess_pipeline.hip,
+    dependency on a kernel: the runtime then uses the DMA engine instead of a blit kernel (hess_copier.hip,
     kDeliverDma, for the same reason).  Buffers grow on demand and are reused from step to step."""
 
     def __init__(self):

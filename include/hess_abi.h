@@ -160,6 +160,11 @@ void hess_default_params(hess_params* p);
  * (TestWin/MultiThreadSIFT.cpp:233-234; ProgramCU::CheckCudaDevice, ProgramCU.cu:3386-3440, rejects the rest). */
 int hess_device_count(void);
 
+/* 1 when the loaded library is the DEVELOPER build (-DHESS_DEV_SWITCHES: schedule A/B switches, fault injection and the
+ * other test hooks read from the environment, hessgpu_amd/csrc/hess_ctx.h), 0 for the shipped library, which reads
+ * HESS_SHARE_DIR / TMPDIR, HESS_COPY_TIMEOUT_S and HESS_DELIVERY only.  No reference counterpart.  (Added in version 4.) */
+int hess_dev_switches(void);
+
 /* Replaces SiftGPU::CreateContextGL/VerifyContextGL -> InitSiftGPU -> new PyramidCU
  * (SiftGPU.cpp:149-227,1516-1539) and ProgramCU::CheckCudaDevice (ProgramCU.cu:3386-3440).
  * `device` is the HIP device ordinal.  Returns NULL on failure. */
@@ -235,8 +240,8 @@ int hess_debug_level(hess_ctx* ctx, int img, int octave, int level, int what, fl
  * (hess_set_keypoints + hess_run_*, or hess_run_keypoints) and is cleared by it. */
 int hess_debug_key_levels(hess_ctx* ctx, const int* levels, int num);
 /* Robustness hook: how many times this context has grown its feature storage after an overflow and run a batch
- * again (the reference grows its lists per image, PyramidCU.cpp:393-397).  The environment variable
- * HESS_INITIAL_CAP=<n> makes a new context start with room for n detections per image so that tests can force it. */
+ * again (the reference grows its lists per image, PyramidCU.cpp:393-397).  In the developer build the environment
+ * variable HESS_INITIAL_CAP=<n> makes a new context start with room for n detections per image so that tests can force it. */
 int hess_debug_regrown(hess_ctx* ctx);
 /* Parity hook: the top Gaussian level of every octave (level dog+1) is nobody's input -- the launch that produces it
  * computes its det-Hessian from the output tile and does NOT write the level to HBM (the reference materialises it,

@@ -1508,7 +1508,7 @@ static int process_image(hess_cpu_ctx* c, const unsigned char* pix, int width, i
   int dim = p->compute_descriptors ? (p->half_sift ? 64 : 128) : 0;
   c->desc_dim = dim;
   /* the pixel order's fixed-point bound assumes luminance in [0, 1] (8- and 16-bit inputs): float pixels are taken as
-   * they are and keep the interleaved order (hess_pipeline.hip: the same rule) */
+   * they are and keep the interleaved order (hess_schedule.hip: the same rule) */
   const int desc_order = (p->descriptor_order == HESS_DESC_ORDER_PIXEL && pixtype == HESS_PIX_F32) ? HESS_DESC_ORDER_INTERLEAVED
                                                                                                    : p->descriptor_order;
   float* desc = NULL;

@@ -20,7 +20,12 @@ def gpu_ctx_factory():
 
     made = []
 
+    # HESS_TEST_DEV_BUILD=1 (tools/robustness.sh): every context of the suite comes from the developer build, which reads
+    # the schedule switches the matrix sets (HESS_NO_TOP_FUSION, HESS_CHAIN_FROM, ...) from the environment
+    dev_default = os.environ.get("HESS_TEST_DEV_BUILD") == "1"
+
     def make(**overrides):
+        overrides.setdefault("dev_switches", dev_default)
         c = hessgpu_amd.HessContext(0, **overrides)
         made.append(c)
         return c

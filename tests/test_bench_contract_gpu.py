@@ -106,8 +106,9 @@ def test_two_rank_control_flow_on_one_gpu(dest, tmp_path):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HESS_BENCH_BACKEND="gloo", HESS_BENCH_SAME_GPU="1")
-    if dest == "file":
-        env.update(HESS_SHARE_FORCE_FILE="1", HESS_SHARE_DIR=str(tmp_path))
+    if dest == "file":   # (HESS_SHARE_FORCE_FILE is a test hook of the developer build: the ranks load that library)
+        import hessgpu_amd
+        env.update(HESS_SHARE_FORCE_FILE="1", HESS_SHARE_DIR=str(tmp_path), HESS_LIB=hessgpu_amd.DEV_LIB_PATH)
     if dest == "host":
         env["HESS_BENCH_SHM_PREFIX"] = "no/such"
     bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--contexts", "2", "--batch", "3", "--no-profile"]

@@ -25,7 +25,7 @@ lum = np.ascontiguousarray(fixtures.load_rgb("640-1.jpg")[..., 1])
 batch = np.stack([lum, lum[::-1].copy(), lum[:, ::-1].copy(), lum])
 o = OracleSession(threads=8, keep_levels=False)
 want = o.run(batch)
-g = hessgpu_amd.HessContext(0)
+g = hessgpu_amd.HessContext(0, dev_switches=True)   # the developer build: HESS_COPIER_FAULT / _ENGINE exist there only
 keep = None
 def run_once():
     global keep
@@ -98,7 +98,7 @@ import fixtures, hessgpu_amd
 
 lum = np.ascontiguousarray(fixtures.load_rgb("640-1.jpg")[..., 1])
 batch = np.stack([lum, lum[::-1].copy(), lum[:, ::-1].copy(), lum])
-g = hessgpu_amd.HessContext(0)
+g = hessgpu_amd.HessContext(0, dev_switches=True)   # the developer build: HESS_COPIER_FAULT / _ENGINE exist there only
 try:
     g.run(batch)
 except hessgpu_amd.HessError as e:
@@ -113,7 +113,7 @@ for call in (lambda: g.run(batch), lambda: g.reserve(lum.shape[1], lum.shape[0],
     else:
         raise SystemExit("a poisoned context accepted another run")
 g.close()            # leaves the copy's buffers and signals alone (they may still be written); must not crash
-g2 = hessgpu_amd.HessContext(0)   # a new context of the same process works
+g2 = hessgpu_amd.HessContext(0, dev_switches=True)   # a new context of the same process works
 n = g2.run(batch)
 assert min(n) > 100, n
 g2.close()

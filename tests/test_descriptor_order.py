@@ -101,7 +101,7 @@ def test_oracle_pixel_order_agrees_with_the_reference_order_within_tolerance(kw)
 
 def test_oracle_pixel_order_keeps_float_orders_for_float_pixels_and_keypoint_lists():
     """The pixel order's fixed-point bound assumes luminance in [0, 1]: float pixels and user keypoint lists are
-    described in the interleaved order (the same rule in hess_pipeline.hip)."""
+    described in the interleaved order (the same rule in hess_schedule.hip)."""
     lum = np.ascontiguousarray(fixtures.load_rgb("640-1.jpg")[..., 1])
     f32 = lum.astype(np.float32) / np.float32(255.0)
     res = []

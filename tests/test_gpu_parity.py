@@ -298,14 +298,14 @@ def test_parity_noise_ragged(gpu_ctx_factory, w, h):
     rng = np.random.RandomState(w * 131 + h)
     img = (rng.rand(2, h, w) * 255).astype(np.uint8)
     kw = dict(dog_threshold=0.0005, edge_threshold=50.0)
-    g = gpu_ctx_factory(**kw)
+    g = gpu_ctx_factory(dev_switches=True, **kw)
     o = OracleSession(threads=8, **kw)
     _compare_all(g, o, img, f"noise {w}x{h}")
 
 
 @pytest.mark.parametrize("mode", ["mirror", "dma", "blit"])
 def test_result_delivery_modes(gpu_ctx_factory, monkeypatch, mode):
-    """Three ways for the results to reach the host (hess_pipeline.hip, kDeliver*): stores of the descriptor kernel
+    """Three ways for the results to reach the host (hess_copier.hip, kDeliver*): stores of the descriptor kernel
     into pinned memory (small batches), a DMA copy issued by the context's copier thread once the kernels are done
     (larger batches), and a device->host copy on the context's stream after hess_wait has read the counts (the
     fallback).  Same results every way, for one image and for a batch, also when modes alternate on one context."""
@@ -323,11 +323,11 @@ def test_result_delivery_modes(gpu_ctx_factory, monkeypatch, mode):
 def test_delivery_in_parts_of_larger_batches(gpu_ctx_factory, monkeypatch, parts):
     """Batches of four or more images delivered by the copier thread get their descriptors in several launches
     (groups of images), a group's results crossing the host link while the next group is computed
-    (hess_pipeline.hip, enqueue(); HESS_DESC_PARTS=n overrides the number of groups, 1 = one launch, one transfer).
+    (hess_schedule.hip, enqueue(); HESS_DESC_PARTS=n overrides the number of groups, 1 = one launch, one transfer).
     Same results, also when a group -- or a single image -- has no features at all, and for an odd batch."""
     if parts:
         monkeypatch.setenv("HESS_DESC_PARTS", parts)
-    g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
+    g = gpu_ctx_factory(dev_switches=bool(parts), truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
     o = OracleSession(threads=8, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=300)
     blobs = [fixtures.synthetic_blobs(320, 240, 70 + i) for i in range(5)]
     flat = np.full((240, 320), 128, np.uint8)
@@ -353,7 +353,7 @@ def test_pinned_input_is_uploaded_beside_the_queues(gpu_ctx_factory, monkeypatch
     if not side:
         monkeypatch.setenv("HESS_NO_SIDE_UPLOAD", "1")
     monkeypatch.setenv("HESS_INITIAL_CAP", "64")     # the first batches overflow and are run again from the device copy
-    g = gpu_ctx_factory(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=400)
+    g = gpu_ctx_factory(dev_switches=True, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=400)
     monkeypatch.delenv("HESS_INITIAL_CAP")
     o = OracleSession(threads=8, keep_levels=False, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=400)
     for nimg, seed in ((5, 0), (8, 20), (2, 40), (5, 60)):
@@ -392,7 +392,7 @@ def test_result_delivery_default_switches_with_batch_size(gpu_ctx_factory):
 def test_feature_storage_grows_on_overflow(gpu_ctx_factory, monkeypatch, mode):
     """The reference grows its per-level lists on demand (SetLevelFeatureNum, PyramidCU.cpp:393-397); here a batch
     that overflows the raw-detection or the feature storage raises a device flag, the storage grows and the batch
-    runs again (hess_pipeline.hip, wait_impl).  HESS_INITIAL_CAP=16 makes a new context start with room for 16
+    runs again (hess_copier.hip, wait_impl).  HESS_INITIAL_CAP=16 makes a new context start with room for 16
     detections per image, so that dense noise at a low threshold overflows both lists -- with every delivery mode,
     for one image and for a batch, with and without top-K."""
     monkeypatch.setenv("HESS_INITIAL_CAP", "16")
@@ -400,7 +400,7 @@ def test_feature_storage_grows_on_overflow(gpu_ctx_factory, monkeypatch, mode):
     rng = np.random.RandomState(11)
     imgs = (rng.rand(3, 120, 200) * 255).astype(np.uint8)
     kw = dict(dog_threshold=0.0005, edge_threshold=50.0)
-    g = gpu_ctx_factory(**kw)
+    g = gpu_ctx_factory(dev_switches=True, **kw)
     o = OracleSession(threads=8, keep_levels=False, **kw)
     n = _compare_all(g, o, imgs, f"grown storage ({mode})", stages=False)
     assert min(n) > 16 * 4 and g.regrown() >= 1          # both lists had to grow (orientations included)
@@ -408,7 +408,7 @@ def test_feature_storage_grows_on_overflow(gpu_ctx_factory, monkeypatch, mode):
     _compare_all(g, o, imgs, f"grown storage ({mode}), again", stages=False)
     assert g.regrown() == grown                           # grow-only: the second run fits
     kt = dict(kw, truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=30)
-    gt = gpu_ctx_factory(**kt)
+    gt = gpu_ctx_factory(dev_switches=True, **kt)
     ot = OracleSession(threads=8, keep_levels=False, **kt)
     _compare_all(gt, ot, imgs[:1], f"grown storage ({mode}), top-K", stages=False)
     assert gt.regrown() >= 1

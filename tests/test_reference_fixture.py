@@ -100,7 +100,7 @@ def test_dog_mode_is_refused_by_the_product():
     hessgpu_amd.load_library()
     p = hessgpu_amd.default_params()
     p.reserved[0] = 2            # the oracle's detector word: the product wants every reserved word zero
-    assert not hessgpu_amd._fns["create"](0, C.byref(p))
+    assert not hessgpu_amd.functions()["create"](0, C.byref(p))
 
 
 def test_default_level_binning_without_the_hook():

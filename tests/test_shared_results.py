@@ -125,7 +125,8 @@ def test_shared_buffers_are_sized_by_need_and_fall_back_to_files(gpu_ctx_factory
             monkeypatch.setenv("HESS_SHARE_FORCE_FILE", "1")
             monkeypatch.setenv("HESS_SHARE_DIR", str(tmp_path))
         name = f"hess_test_need_{os.getpid()}_{int(forced)}"
-        c = gpu_ctx_factory(truncate_method=3, feature_count_threshold=300)
+        # (HESS_SHARE_FORCE_FILE is a test hook of the developer build)
+        c = gpu_ctx_factory(dev_switches=forced, truncate_method=3, feature_count_threshold=300)
         c.share_results(name)
         assert c.run(imgs) == counts
         gk, gd, kb, db = c.shared_results_info()
