@@ -90,7 +90,7 @@ void hess_destroy(hess_ctx* c) {
   DevBuf* bufs[] = {&c->gauss, &c->deth, &c->got, &c->input_f32, &c->upsampled, &c->stage, &c->zeroed, &c->rowoff,
                     &c->level_count, &c->raw_total, &c->found, &c->task_count, &c->raw, &c->sel, &c->sel_total,
                     &c->recs, &c->ocount, &c->foffset, &c->fsrc, &c->feat_total, &c->feat_first, &c->img_base,
-                    &c->keys, &c->desc};
+                    &c->keys, &c->desc, &c->prime_px};
   // A poisoned context (a DMA copy that was lost may still be in flight or land late) deliberately leaks the copy's
   // sources and targets -- result buffers on both sides and the pixel staging area -- rather than hand memory that may
   // still be written back to the allocator; a shared result buffer stays mapped for the same reason.
@@ -160,21 +160,27 @@ static int prime(hess_ctx* c, int width, int height, int batch) {
   }
   static const bool no_dry = dev_env("HESS_NO_PRIME_BATCH") != nullptr;
   const long long shape = ((long long)width << 40) ^ ((long long)height << 16) ^ batch;
-  if (!no_dry && c->batch == 0 && c->user_keys.empty() && c->primed_shape != shape) {
+  const bool primed = std::find(std::begin(c->primed_shapes), std::end(c->primed_shapes), shape) != std::end(c->primed_shapes);
+  if (!no_dry && c->batch == 0 && c->user_keys.empty() && !primed) {
+    // The scratch image belongs to the context (grow-only, freed with it): a hipMalloc / hipFree pair per call would
+    // synchronise the whole device under the other contexts of a pipelining process.  The dry batch takes the settings of a
+    // SUBMITTED batch (what a caller who reserves and then pipelines gets); a caller of hess_run_* with one or two images
+    // takes the latency settings, whose first batch is then primed only as far as the two forms share launches.
     const size_t bytes = (size_t)batch * width * height;
-    void* px = nullptr;
-    if (hipMalloc(&px, bytes + 16) != hipSuccess) { (void)hipGetLastError(); return 0; }  // no room for the scratch image: no dry batch
+    if (ensure(c, c->prime_px, bytes + 16)) { (void)hipGetLastError(); c->err.clear(); return 0; }  // no room for the scratch image: no dry batch
+    void* const px = c->prime_px.p;
     int rc = 0;
     if (hipMemsetAsync(px, 0, bytes, c->st) != hipSuccess) rc = HESS_ERR_DEVICE;
     const PendingRun r{px, width, height, width, batch, HESS_FMT_LUM, HESS_PIX_U8, (size_t)width * height, 0.0, false, false};
     if (!rc) rc = submit_impl(c, r);
     if (!rc) rc = wait_impl(c, r);
     (void)hipStreamSynchronize(c->st);
-    (void)hipFree(px);
     c->batch = c->pyramid_batch = 0;  // a dry batch leaves neither results nor a current image
     memset(c->timing, 0, sizeof(c->timing));
-    if (rc) return rc;
-    c->primed_shape = shape;
+    // A dry batch that fails does not fail the reservation (the buffers exist; the first real batch will say what is
+    // wrong, if anything still is) -- unless it poisoned the context, which refuse_poisoned() reports on the next call.
+    if (rc) { (void)hipGetLastError(); return 0; }
+    c->primed_shapes[c->primed_next++ % 4] = shape;  // the last four shapes: alternating shapes are primed once each
   }
   return 0;
 }
@@ -344,7 +350,7 @@ int hess_submit_host(hess_ctx* c, const void* pixels, int width, int height, int
     Stager& sg = c->sg;
     const size_t chunk = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)256 << 10, ((bytes / 4 + 65535) >> 16) << 16));
     const int nchunk = (int)((bytes + chunk - 1) / chunk);
-    const bool helped = bytes >= ((size_t)8 << 20) && nchunk > 1;
+    const bool helped = bytes >= policy::kStagerHelpFrom && nchunk > 1;
     if (helped) stager_start(sg);
     try {
       if ((int)sg.state.size() < nchunk) { std::vector<std::atomic<int>> grown(nchunk); sg.state.swap(grown); }

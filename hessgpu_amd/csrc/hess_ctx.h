@@ -68,6 +68,38 @@ struct EventPair {
 };
 
 
+// The schedule's thresholds, in one place.  Each was set by a same-call A/B on MI355X; the measurement is named beside it
+// (files under profiles/, sections of DESIGN.md).  The developer build can override the ones marked (dev).
+namespace policy {
+// Batches up to this many images handed over by a caller who WAITS (hess_run_*) are latency cases: they take the chain
+// launches for the small octaves, the short scan segments and the descriptor kernel's own host stores.  A pair SUBMITTED
+// asynchronously (hess_submit_*) counts as a throughput batch: 17.0 - 17.3 against 12.3 - 12.6 Gpix/s for six pipelined
+// contexts (round 5, DESIGN.md "Latency and throughput settings").
+constexpr int kLatencyBatch = 2;            // (dev: HESS_MIRROR_MAX_BATCH)
+// ... and only while the results of the context's last batch stayed within this: beyond it the kernel's stores wait for the
+// host link (a 4096^2 image's 28 MB: 0.77 ms for the mirroring launch against 0.47 for the plain one + DMA, round 6).
+constexpr size_t kMirrorMaxBytes = (size_t)16 << 20;   // (dev: HESS_MIRROR_MAX_MB)
+// Octaves whose planes of the whole batch are at most this many pixels get levels 1..3 from ONE chain launch (latency
+// batches only): below two 960 x 540 planes a level launch is a few dozen workgroups that mostly wait -- one 1080p image 0.400
+// -> 0.334 ms; for larger batches the chain loses 2 - 4 % pipelined (profiles/r05_experiments/chain_stamps_pipelined.txt).
+constexpr long long kChainMaxPixels = 2LL * 960 * 540;   // (dev: HESS_CHAIN_FROM forces the first chained octave)
+// Rows per wavefront segment of the streaming extrema scan: kStreamRows (24, hess_dev.h) for throughput batches, half of it
+// for latency batches (twice the wavefronts, each half as long: the scan of one image is a few hundred wavefronts).
+constexpr int kLatencyStreamRowsDiv = 2;    // (dev: HESS_STREAM_ROWS)
+// A batch of at least this many images delivered by the copier gets its descriptors in two launches over halves of the
+// images: the first half's results cross the host link under the second half's kernel (0.53 ms of transfer for eight
+// 1080p images leaves the critical path; four groups: -1 % pipelined).  profiles/r03_experiments, DESIGN.md "Result delivery".
+constexpr int kSplitDescriptorsFrom = 4;    // (dev: HESS_DESC_PARTS)
+// ONE image delivered by the copier (a large one) gets four launches over quarters of its feature list, for the same
+// reason: 2.09 -> 1.7 ms per 4096^2 image (profiles/r05_experiments/large_image_delivery.txt).
+constexpr int kLargeImageParts = 4;
+// Pinned result buffers hold the worst case up front while that stays below this; beyond it they grow by need.
+constexpr size_t kHostWorstCaseMax = (size_t)512 << 20;
+// Pageable input of at least this size is staged into pinned memory with the helper threads (hess_submit_host): below it
+// starting the helpers costs more than the copy (profiles/r03_f_host_path.json).
+constexpr size_t kStagerHelpFrom = (size_t)8 << 20;
+}  // namespace policy
+
 }  // namespace hess
 
 using namespace hess;
@@ -211,12 +243,12 @@ struct hess_ctx {
   int delivery = kDeliverMirror;   // of the submitted batch (choose_delivery)
   int nparts = 1, part_end[Copier::kMaxParts] = {0, 0, 0, 0};  // the submitted batch's descriptor launches (groups of images)
   bool part_features = false;      // ... or, for one large image, ranges of its features (DescParams::part)
-  size_t mirror_max_bytes = (size_t)16 << 20;  // HESS_MIRROR_MAX_MB: result bytes (of the context's last batch) up to which a small batch uses the in-kernel mirror
+  size_t mirror_max_bytes = policy::kMirrorMaxBytes;   // (dev: HESS_MIRROR_MAX_MB)
   size_t last_result_bytes = 0;    // keypoints + descriptors the last batch delivered, and its size
   int last_result_batch = 0;
   std::atomic<bool> caller_waits{false};  // inside hess_run_* (submit + wait in one call; read by the copier thread, too)
   int delivery_pref = -1;          // HESS_DELIVERY=mirror|dma|blit (-1 = by batch size, see plan())
-  int mirror_max_batch = 2;        // HESS_MIRROR_MAX_BATCH: batches up to this size use the in-kernel mirror
+  int mirror_max_batch = policy::kLatencyBatch;        // (dev: HESS_MIRROR_MAX_BATCH)
   int regrown = 0;                 // times the feature storage was grown after an overflow (hess_debug_regrown)
   int seen_features = 0;           // largest per-image feature count of the last finished batch (0: none yet): sizes the descriptor grid
   int cap_init = 0;                // HESS_INITIAL_CAP: initial raw/feature capacity (developer switch for the grow path)
@@ -235,7 +267,9 @@ struct hess_ctx {
   // its targets -- the pinned result buffers, the pixel staging area -- must neither be reused nor freed.  The context
   // refuses every further run (HESS_ERR_DEVICE) and hess_destroy leaves those buffers and the signals alone.
   std::atomic<bool> poisoned{false};
-  long long primed_shape = -1;     // (width, height, batch) of the dry batch hess_reserve has run (prime())
+  long long primed_shapes[4] = {-1, -1, -1, -1};  // shapes (width, height, batch) hess_reserve has run a dry batch for
+  unsigned primed_next = 0;
+  DevBuf prime_px;                 // the dry batch's scratch image (zero pixels)
   PendingRun* pend = nullptr;      // batch submitted with hess_submit_device and not yet waited for
   // user-supplied keypoint list (SiftPyramid::SetKeypointList): used by the next run, then cleared
   std::vector<hess_keypoint> user_keys;
@@ -266,6 +300,7 @@ struct hess_ctx {
 
 // ---- shared by the host-side files (namespace hess) ----
 namespace hess {
+
 
 void set_err(hess_ctx* c, const char* fmt, ...);
 

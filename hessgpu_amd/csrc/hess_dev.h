@@ -174,6 +174,7 @@ struct GaussJob {
 void launch_gauss_job(hipStream_t st, const GaussJob& j, int batch);
 // Levels 0 and 1 of octave 0 from u8 pixels in one launch (level 0 stays in LDS; dst0: stored as well); false: tap counts
 // not instantiated.
+bool gauss_first_available(const Taps& taps0, const Taps& taps1);  // the tap counts launch_gauss_first is instantiated for
 bool launch_gauss_first(hipStream_t st, const uint8_t* pixels, long long pitch, long long img_stride, const Taps& taps0,
                         const GaussJob& level1, float* dst0, int batch);
 // Two independent level launches in one grid (the top level of an octave and level 1 of the next); false if the pair of

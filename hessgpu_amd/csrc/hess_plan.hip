@@ -246,7 +246,7 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
   {  // the scan's unordered detections: every scan task's slots + the image's spill list (hess_dev.h, DetectStore);
      // tasks for the shortest segments a batch may be scanned with (enqueue(): batches of one or two images, HESS_STREAM_ROWS)
     int ntask = extrema_tasks(g);
-    for (int rows : {kStreamRows / 2, c->stream_rows}) {
+    for (int rows : {kStreamRows / policy::kLatencyStreamRowsDiv, c->stream_rows}) {
       if (rows <= 0) continue;
       Geom gr = g;
       set_stream_rows(gr, rows);
@@ -274,7 +274,7 @@ int plan_inner(hess_ctx* c, int width, int height, int batch) {
     // worst case B * cap_feat: 79 MB per context, 3.8 - 4.4 GB of /dev/shm for a node's six or seven contexts x eight
     // ranks, where the results are 24 MB per context; the copier (or hess_wait) grows them under a new generation when a batch needs more.
     c->share_by_need = c->share_dir && B > c->mirror_max_batch && c->delivery_pref != kDeliverMirror;
-    c->host_fits = !c->share_by_need && host_bytes <= ((size_t)512 << 20);
+    c->host_fits = !c->share_by_need && host_bytes <= policy::kHostWorstCaseMax;
     if (c->host_fits) {
       if ((rc = ensure(c, c->h_keys, (size_t)B * cap_feat * sizeof(HostKeypoint), true))) return rc;
       if (c->dim && (rc = ensure(c, c->h_desc, (size_t)B * cap_feat * c->dim * 4, true))) return rc;

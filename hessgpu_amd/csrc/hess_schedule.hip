@@ -80,7 +80,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dp.subpixel = p.subpixel;
   Geom gx = g;  // the extrema scan's segment length
   if (c->stream_rows > 0) set_stream_rows(gx, c->stream_rows);      // HESS_STREAM_ROWS (A/B switch; a multiple of 3)
-  else if (batch <= 2) set_stream_rows(gx, kStreamRows / 2);        // one or two images: shorter segments, twice the wavefronts
+  else if (batch <= policy::kLatencyBatch) set_stream_rows(gx, kStreamRows / policy::kLatencyStreamRowsDiv);  // shorter segments, twice the wavefronts
   if (!(user_mode && c->user_on_current)) {  // SIFT_SKIP_FILTERING: the resident pyramid is reused
   // ---- input + pyramid (BuildPyramid, PyramidCU.cpp:1486-1558) ----
   const bool direct_u8 = (format == HESS_FMT_LUM && pixtype == HESS_PIX_U8 && c->ds == 0 && c->has_taps0 &&
@@ -169,8 +169,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       chain_from = g.noct;
       // (a PAIR of images handed over by hess_submit_* -- a caller who pipelines -- gets the level-by-level launches and
       //  the copier's delivery like a larger batch: 17.0 - 17.3 against 12.3 - 12.6 Gpix/s for six pipelined contexts)
-      if (batch == 1 || (batch == 2 && c->caller_waits))
-        for (int o = g.noct - 1; o >= 1 && (long long)batch * g.o[o].plane <= 2LL * 960 * 540; o--) chain_from = o;
+      if (batch == 1 || (batch <= policy::kLatencyBatch && c->caller_waits))
+        for (int o = g.noct - 1; o >= 1 && (long long)batch * g.o[o].plane <= policy::kChainMaxPixels; o--) chain_from = o;
     }
     if (chain_from > g.noct) chain_from = g.noct;
   }
@@ -205,7 +205,8 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       continue;
     }
     bool first_fused = false;  // levels 0 and 1 of octave 0 came out of one launch (level 0 never written)
-    if (o == 0 && direct_u8 && c->has_taps0 && !c->no_first_fusion && s.level_max >= 2 && s.level_ds != 1 && chain_from != 0) {
+    if (o == 0 && direct_u8 && c->has_taps0 && !c->no_first_fusion && s.level_max >= 2 && s.level_ds != 1 && chain_from != 0 &&
+        gauss_first_available(c->taps0, s.taps[1])) {  // (decided BEFORE the profile scope: a refused launch must not book bytes)
       // u8 pixels -> level 0 (LDS) -> level 1, det-H of level 0: the level-0 plane is nobody's input but level 1's
       const GaussJob j1 = level_job(0, 1);
       ProfScope ps(c, HESS_K_GAUSS, (double)batch * og.plane * (1.0 + 4.0 + 4.0), HESS_K_GAUSS_OCT0,
@@ -385,9 +386,10 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   // quarters of its feature list, for the same reason (a 4096^2 image with 102 k half descriptors: 28 MB, 0.58 ms on the
   // link; 2.09 -> 1.7 ms per image on one context).
   {
-    int want = batch >= 4 ? 2 : 1;
+    int want = batch >= policy::kSplitDescriptorsFrom ? 2 : 1;
     c->part_features = false;
-    if (batch == 1 && c->delivery == kDeliverDma) { want = Copier::kMaxParts; c->part_features = true; }
+    static_assert(policy::kLargeImageParts <= Copier::kMaxParts, "parts of one image");
+    if (batch == 1 && c->delivery == kDeliverDma) { want = policy::kLargeImageParts; c->part_features = true; }
     if (c->desc_parts > 0) want = std::max(1, std::min<int>(Copier::kMaxParts, c->part_features ? c->desc_parts : std::min(batch, c->desc_parts)));
     if (c->delivery != kDeliverDma || !c->cp.ev_part[0]) want = 1;
     if (want == 1) c->part_features = false;

@@ -1162,9 +1162,11 @@ bool launch_pair_b(hipStream_t st, const GaussArgs& a, const GaussArgs& b, int r
 // Octave 0 of u8 pixels: level 0 (taps0, in LDS only unless dst0 is given) and level 1 (the job: its dst, taps, det-H
 // plane of its source = level 0) in one launch.  Instantiated for the reference's default schedule (13 and 11 taps);
 // false: not this pair of tap counts -- launch level 0 and level 1 one after the other.
+bool gauss_first_available(const Taps& taps0, const Taps& taps1) { return (taps0.fw >> 1) == 6 && (taps1.fw >> 1) == 5; }
+
 bool launch_gauss_first(hipStream_t st, const uint8_t* pixels, long long pitch, long long img_stride, const Taps& taps0,
                         const GaussJob& level1, float* dst0, int batch) {
-  if ((taps0.fw >> 1) != 6 || (level1.taps.fw >> 1) != 5 || !level1.deth_src || level1.got_src || level1.deth_dst ||
+  if (!gauss_first_available(taps0, level1.taps) || !level1.deth_src || level1.got_src || level1.deth_dst ||
       level1.decim_dst || (pitch % 4) != 0 || (img_stride % 4) != 0)
     return false;
   GaussArgs a = job_args(level1, batch);

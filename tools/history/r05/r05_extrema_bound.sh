@@ -8,9 +8,9 @@ for mode in fill read; do
   $R/tools/micro/strided_streams $mode > $OUT/strided_$mode.txt 2>&1
   cat $OUT/strided_$mode.txt
   for ctr in WRITE_SIZE FETCH_SIZE; do
-    rm -rf /tmp/ss_$mode_$ctr
+    rm -rf /tmp/ss_${mode}_$ctr
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/ss_${mode}_$ctr -- $R/tools/micro/strided_streams $mode > /dev/null 2>&1
-    python3 - $(find /tmp/ss_${mode}_$ctr -name '*counter_collection.csv') $ctr $mode <<'PY'
+    python3 - $(find /tmp/ss_${mode}_$ctr -name '*counter_collection.csv' | head -1) $ctr $mode <<'PY'
 import csv, sys, collections, re
 tot, n = collections.Counter(), collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
