@@ -962,7 +962,9 @@ def _host_cores():
     return max(1, min(n, 16))
 
 
-PARITY_TOL_VS_REFERENCE_ORDER = 1e-5   # unit-norm descriptors, 1080p; the north star allows 1e-4 (tests/test_gpu_parity.py: TOL_ORDER)
+# unit-norm descriptors of the bench's 1080p image: 6e-6 measured.  (include/hess_abi.h lists the measured distance per
+# config; tests/test_gpu_parity.py bounds all of them, 4096^2's 1.6e-5 included, by TOL_ORDER = 3e-5; north star 1e-4.)
+PARITY_TOL_VS_REFERENCE_ORDER = 1e-5
 PARITY_TOL_VS_FORMULA = 1e-6           # against the reference's formula in double precision (oracle, HESS_ORACLE_DESC_EXACT = 3)
 _parity_detail = {}
 

@@ -65,12 +65,18 @@ enum { HESS_TRUNC_HIGHEST_0 = 0, HESS_TRUNC_HIGHEST_1 = 1, HESS_TRUNC_LOWEST = 2
  *                          keypoint's frame: the reference re-evaluates it for each of the up to four cells it belongs
  *                          to) and adds its weight to <= 2 x 2 cells x 2 bins in 32-bit fixed point with a per-keypoint
  *                          power-of-two scale -- integer sums, so the result does not depend on the order of the
- *                          additions (any parallel schedule gives the same bits; the oracle's plain loop does).  Within
- *                          6e-6 of SEQUENTIAL on unit-norm descriptors (measured; most of it SEQUENTIAL's own float
- *                          rounding: a float64 evaluation of the reference's formula is 20 x closer to PIXEL), bounded by
- *                          1e-5 in the tests; north star 1e-4.  Descriptor kernel a further 21 % faster, whole path + 9 %.
- *                          Needs luminance in [0, 1] for its overflow bound: float pixels (HESS_PIX_F32, taken as they
- *                          are) and user keypoint lists are described in the INTERLEAVED order instead. */
+ *                          additions (any parallel schedule gives the same bits; the oracle's plain loop does).
+ *                          Distance to SEQUENTIAL on unit-norm descriptors, measured per BASELINE config
+ *                          (tests/test_gpu_parity.py): 640x480 (configs[2]) 2.5e-6, 1920x1080 (configs[1]) 6e-6, 4096x4096
+ *                          (configs[4]) 1.6e-5 -- ONE bound for all of them in the tests, TOL_ORDER = 3e-5 (bench.py checks
+ *                          its 1080p image against 1e-5); north star 1e-4.  Most of the distance is SEQUENTIAL's own float
+ *                          rounding (it rounds every cell centre at the magnitude of the image coordinate: 1e-5 relative
+ *                          at x = 4000): a float64 evaluation of the reference's formula is within 2.5e-7 of PIXEL on all
+ *                          three (TOL_EXACT = 1e-6).  Descriptor kernel a further 21 % faster, whole path + 9 %.
+ *                          Needs luminance in [0, 1] for its overflow bound, so two inputs keep the INTERLEAVED order --
+ *                          permanently, not as a transition: float pixels (HESS_PIX_F32, taken as they are) and user
+ *                          keypoint lists (hess_set_keypoints: any scale at any level).  All three orders have a bitwise
+ *                          oracle restatement and stay in tools/fuzz_parity.py and the robustness matrix. */
 enum { HESS_DESC_ORDER_INTERLEAVED = 0, HESS_DESC_ORDER_SEQUENTIAL = 1, HESS_DESC_ORDER_PIXEL = 2 };
 
 /* Pixel formats accepted by hess_run_* (the GL enums of SiftGPU::RunSIFT(w,h,data,fmt,type)
