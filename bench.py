@@ -504,8 +504,13 @@ def main():
             # the dominant kernel of the committed kernel trace (top row of the rocprofv3 statistics of the last profiled
             # round), priced with the bytes of that profiled run: a copy, so that the line and the trace name the same kernel
             top = _profile_json("kernel_stats_top.json")
-            if top:   # (not measured by this run: a verbatim copy of the committed file, marked as such)
+            if top:   # (not measured by this run: a verbatim copy of the committed file, marked as such -- and as stale when it
+                      #  was measured on other kernel sources than this run's)
                 out["roofline_by_rocprof"] = dict(top, from_committed_profile=True)
+            stale = [n for n in ("gauss_traffic.json", "descriptor_counters.json", "kernel_stats_top.json") if (_profile_json(n) or {}).get("stale")]
+            if stale:
+                out["committed_profiles_stale"] = {"files": stale, "effect": "valu / traffic entries derived from them are left off this line",
+                                                   "reason": (_profile_json(stale[0]) or {}).get("stale_reason")}
         if host is not None:
             out.update(host)
         if api is not None:
@@ -917,18 +922,36 @@ def rooflines(prof, steps, timed_keys, images, prof_other=None, mirror=False, or
     return out
 
 
+_sources_sha16 = []
+
+
 def _profile_json(name):
-    """A committed summary under profiles/, if it exists."""
+    """A committed summary under profiles/, if it exists.  Summaries of kernel profiles record the sources they were
+    measured on (`kernel_sources_sha16`, hessgpu_amd/build.py sources_digest()); one measured on OTHER sources than the ones
+    this run executes comes back with "stale": True -- numbers derived from it are then left off the line."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)
+            d = json.load(f)
     except Exception:
         return None
+    if isinstance(d, dict) and "kernel_sources_sha16" in d:
+        if not _sources_sha16:
+            try:
+                from hessgpu_amd import build
+                _sources_sha16.append(build.sources_digest())
+            except Exception:
+                _sources_sha16.append(None)
+        if _sources_sha16[0] and d["kernel_sources_sha16"] != _sources_sha16[0]:
+            d = dict(d, stale=True, stale_reason=f"measured on kernel sources {d['kernel_sources_sha16']} (commit {d.get('commit', '?')}), "
+                                                 f"this run executes {_sources_sha16[0]}")
+    return d
 
 
 def _profile_value(name, key):
-    """A number from a committed PMC summary under profiles/, if one exists."""
-    return (_profile_json(name) or {}).get(key)
+    """A number from a committed PMC summary under profiles/, if one exists and was measured on the sources this run
+    executes (chip constants -- valu_peak.json, hbm_mix.json -- carry no source hash and are always used)."""
+    d = _profile_json(name) or {}
+    return None if d.get("stale") else d.get(key)
 
 
 def bad_fractions(node, path=""):

@@ -35,6 +35,22 @@ DEV_SWITCH_SOURCES = ("hess_abi.hip", "hess_copier.hip", "hess_shared.hip")  # t
 FILE_FLAGS = {"k_feature.hip": ["-fno-slp-vectorize"]}
 
 
+def sources_digest():
+    """First 16 hex digits of the SHA-256 over the sources of libhessgpu.so (csrc/*.hip, *.h, sorted by name) and the
+    compiler flags: what a committed profile (profiles/*.json, `kernel_sources_sha16`) was measured on.  bench.py compares it
+    with the sources it runs and marks numbers copied from a profile of other sources as stale."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(f.read())
+    h.update(" ".join(CXXFLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(FILE_FLAGS.items())]).encode())
+    return h.hexdigest()[:16]
+
+
 def _newer(src_list, target):
     if not os.path.exists(target):
         return True

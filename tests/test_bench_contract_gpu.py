@@ -33,7 +33,7 @@ def test_bench_json_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_secondary", "cpu_baseline",
               "value_host_to_host", "value_device_resident", "latency_ms_single_image", "parity_checked",
-              "kernel_ms_per_step", "value_siftgpu_api_1thread", "value_siftgpu_api_threads", "configs4"):
+              "kernel_ms_per_step", "value_siftgpu_api_1thread", "value_siftgpu_api_threads", "configs4", "real_images", "matcher"):
         assert k in d, k
     assert d["unit"] == "Mpix/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -50,7 +50,8 @@ def test_bench_json_line():
     assert kernels == {"gauss_kernel", "descriptor_pixel_kernel<false>"} and rf["ms_per_step"] >= d["roofline_secondary"]["ms_per_step"]
     dk = rf if rf["kernel"].startswith("descriptor") else d["roofline_secondary"]
     assert dk["with_host_mirror"]["kernel"] == "descriptor_pixel_kernel<true>" and dk["with_host_mirror"]["avg_launch_us"] > 0
-    assert dk["valu"]["peak"] == 1228.8 and 0 < dk["valu"]["frac"] < 1
+    if "committed_profiles_stale" not in d:   # (the vector-issue entries come from a committed PMC pass: left off when that pass
+        assert dk["valu"]["peak"] == 1228.8 and 0 < dk["valu"]["frac"] < 1   #  was of other kernel sources than this run's)
     gk = rf if rf["kernel"].startswith("gauss") else d["roofline_secondary"]
     o0 = gk["octave0_launches"]  # the Gaussian launches of octave 0, timed apart: the bandwidth-bound part of the stage
     assert o0["launches"] > 0 and 0 < o0["frac"] < 1 and o0["frac"] > gk["frac"] and 0.5 < o0["share_of_stage_bytes"] < 1
@@ -64,6 +65,13 @@ def test_bench_json_line():
     rr = d["roofline_by_rocprof"]
     assert rr["kernel"].startswith(("descriptor", "gauss")) and rr["avg_launch_us"] > 0 and rr["source"].startswith("profiles/")
     assert rr["from_committed_profile"] is True
+    assert ("stale" in rr) == ("committed_profiles_stale" in d and "kernel_stats_top.json" in d["committed_profiles_stale"]["files"])
+    # the legs of round 6: the reference's own photographs and the matcher
+    ri = d["real_images"]
+    big = next(v for k, v in ri.items() if k.startswith("1600.jpg"))
+    assert big["Mpix_per_s_three_contexts"] > 0 and big["features_per_image_mean"] > 1000 and "gauss" in big["kernel_ms_per_step"]
+    mt = d["matcher"]
+    assert mt["bound"] == "mfma_i8" and 0 < mt["frac"] < 1 and mt["parity_checked"] is True and mt["8192x8192"]["TMAC_per_s"] > 0
     assert d["parity_checked"] is True                       # image 0 of the timed run == the oracle, bit for bit
     par = d["parity"]   # ... in the SAME summation order bit for bit, and against the reference's order within the tolerance
     assert par["bitwise_vs_oracle_in_the_same_order"] is True and par["keypoints_bitwise_vs_oracle_in_the_reference_order"] is True

@@ -15,8 +15,26 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def provenance(d):
+    """What the profile was measured on: the source hash the GPU box computed from the snapshot it ran
+    (tools/profile_round.sh -> provenance.json) and the commit checked out here at publishing time."""
+    import subprocess
+    out = {}
+    try:
+        out.update(json.load(open(os.path.join(d, "provenance.json"))))
+    except Exception:
+        pass
+    try:
+        out["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        out["commit_tree_dirty"] = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "hessgpu_amd/csrc"], capture_output=True, text=True).stdout.strip())
+    except Exception:
+        pass
+    return out
+
+
 def main():
     d, tag = sys.argv[1], sys.argv[2]
+    prov = provenance(d)
     bench = json.loads(open(os.path.join(d, "bench_ctx1.json")).read().strip().splitlines()[-1])
     traffic = json.load(open(os.path.join(d, "traffic.json")))
     rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(d, "counters.csv")))}
@@ -38,6 +56,7 @@ def main():
     traffic["valu_insts_steps_in_pass"] = steps
     if not (1.0e6 < traffic["valu_insts_per_image"] < 1.0e8):   # a 1080p pyramid is 1.5e7 - 2.5e7 vector instructions
         raise SystemExit(f"make_profile_json: {traffic['valu_insts_per_image']} vector instructions per image is not plausible")
+    traffic.update(prov)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "gauss_traffic.json"), "w"), indent=1)
     dd = bench["roofline"] if bench["roofline"]["kernel"].startswith("descriptor") else bench["roofline_secondary"]
     dk = dd["kernel"].split(" (")[0]  # the form the benched batch size uses: descriptor_kernel<false> (copier delivery) or <true> (host mirror)
@@ -59,11 +78,13 @@ def main():
         "hbm_bytes_per_launch": tr["hbm_bytes_per_launch_corrected"] if tr else None,
         "algorithmic_bytes_per_launch": dd["algorithmic_bytes_per_launch"],
     }
+    out.update(prov)
     json.dump(out, open(os.path.join(ROOT, "profiles", "descriptor_counters.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
     extrema_table(d, tag, rows, traffic)
     top = kernel_stats_top(d, tag, bench)
     if top:
+        top.update(prov)
         json.dump(top, open(os.path.join(ROOT, "profiles", "kernel_stats_top.json"), "w"), indent=1)
         print(json.dumps(top, indent=1))
 

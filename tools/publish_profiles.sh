@@ -20,4 +20,11 @@ cp $T/overlap_default.txt $P/${TAG}_overlap_contexts6.txt
 cp $T/stats_ctx1/*/*kernel_stats.csv $P/${TAG}_kernel_stats_contexts1.csv
 cp $T/stats_default/*/*kernel_stats.csv $P/${TAG}_kernel_stats_contexts6.csv
 cp $T/stats_default/*/*memory_copy_stats.csv $P/${TAG}_memory_copy_stats_contexts6.csv
+cp $T/stats_cfg4/*/*kernel_stats.csv $P/${TAG}_kernel_stats_configs4.csv
+cp $T/counters_cfg4.csv $P/${TAG}_counters_configs4.csv
+cp $T/cfg4.json $P/${TAG}_configs4_under_rocprof.json
+cp $T/stats_match/*/*kernel_stats.csv $P/${TAG}_kernel_stats_matcher.csv
+cp $T/counters_match.csv $P/${TAG}_counters_matcher.csv
+cp $T/match.txt $P/${TAG}_matcher_under_rocprof.txt
+cp $T/provenance.json $P/${TAG}_provenance.json
 grep -l consistency_error $P/${TAG}_bench_*.json && echo "^ lines with consistency_error: run the round again" || echo "published $TAG"
