@@ -327,8 +327,10 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const uint8_t* des1, in
   for (int sup = s0; sup < s1; sup++) {
     const int cur = (sup - s0) & 1;
     if (sup + 1 < s1) stage_load(sup + 1);  // in flight while this super tile is multiplied
-    // (one tile at a time: a software pipeline over the tiles -- the next tile's MFMAs issued between this tile's folds --
-    // needs 260 registers, spills at two wavefronts per SIMD and runs 9 % slower: profiles/r06_experiments/matcher.txt)
+    // (one tile at a time: a software pipeline over the tiles -- the next tile's fragments read and its MFMAs issued between
+    // this tile's folds -- was measured twice and lost both times: unrolled it needs 260 registers and spills (- 9 %),
+    // rolled it fits 191 and runs 3 % slower than this loop, whose waits the SIMD's other wavefront fills:
+    // profiles/r06_experiments/matcher.txt)
 #pragma unroll 1
     for (int tt = 0; tt < 4; tt++) {
       const int tl = (sup - s0) * 4 + tt;     // tile index in the segment

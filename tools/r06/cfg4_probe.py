@@ -27,7 +27,7 @@ def main():
     runs = int(sys.argv[sys.argv.index("--runs") + 1]) if "--runs" in sys.argv else 5
     img = fixtures.synthetic_blobs(S, S, 0)
     d = torch.from_numpy(img[None]).to("cuda:0")
-    nctx = 1 if "--quick" in sys.argv else 3
+    nctx = 1 if "--quick" in sys.argv else (int(sys.argv[sys.argv.index("--contexts") + 1]) if "--contexts" in sys.argv else 3)
     ctxs = [hessgpu_amd.HessContext(0, tex_max_dim=4096, half_sift=1, truncate_method=_abi.TRUNC_TOPK,
                                     feature_count_threshold=65536) for _ in range(nctx)]
     for c in ctxs:
@@ -36,16 +36,16 @@ def main():
     c = ctxs[0]
     keys = c.fetch(0)[0]
     out = {"features": int(c.count(0))}
-    if nctx == 3:
+    if nctx >= 2:
         t0 = time.perf_counter()
         for _ in range(10):
             c.run_device(d.data_ptr(), 1, S, S)
         out["ms_one_context"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
-        steps, inflight = 30, []
+        steps, inflight = 60, []
         t0 = time.perf_counter()
         for i in range(steps):
-            x = ctxs[i % 3]
-            if len(inflight) == 3:
+            x = ctxs[i % nctx]
+            if len(inflight) == nctx:
                 inflight.pop(0).wait()
             x.submit_device(d.data_ptr(), 1, S, S)
             inflight.append(x)
