@@ -622,7 +622,7 @@ def configs4_leg(local_rank, torch):
     img = fixtures.synthetic_blobs(S, S, 0)   # the generator scales its blob count with the area
     d = torch.from_numpy(img[None]).to(torch.device("cuda", local_rank))
     ctxs = [hessgpu_amd.HessContext(local_rank, tex_max_dim=4096, half_sift=1, truncate_method=_abi.TRUNC_TOPK,
-                                    feature_count_threshold=65536) for _ in range(3)]
+                                    feature_count_threshold=65536) for _ in range(5)]
     for c in ctxs:
         c.reserve(S, S, 1)
         c.run_device(d.data_ptr(), 1, S, S)
@@ -633,23 +633,36 @@ def configs4_leg(local_rank, torch):
     for _ in range(reps):
         ctxs[0].run_device(d.data_ptr(), 1, S, S)
     lat = (time.perf_counter() - t0) / reps
-    steps, inflight = 30, []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        c = ctxs[i % 3]
-        if len(inflight) == 3:
+    def pipelined(n, steps=40):
+        inflight = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            c = ctxs[i % n]
+            if len(inflight) == n:
+                inflight.pop(0).wait()
+            c.submit_device(d.data_ptr(), 1, S, S)
+            inflight.append(c)
+        while inflight:
             inflight.pop(0).wait()
-        c.submit_device(d.data_ptr(), 1, S, S)
-        inflight.append(c)
-    while inflight:
-        inflight.pop(0).wait()
-    dt = (time.perf_counter() - t0) / steps
+        return (time.perf_counter() - t0) / steps
+
+    pipelined(5, 10)
+    dt = pipelined(3)
+    dt5 = pipelined(5)   # (same call, 2 .. 6 contexts: 11.3 / 11.1 - 12.2 / 12.8 / 13.6 / 13.5 Gpix/s, tools/r06/cfg4_ctx.sh)
+    # per-kernel split of the SUBMITTED form (what the pipelined figures above run: copier delivery, the descriptors in four
+    # launches over quarters of the list), one context, single stream; beside it the descriptor launch of the synchronous
+    # form (hess_run_device keeps the descriptor kernel's own host stores: 28 MB through the link inside the kernel)
     c = ctxs[0]
     c.profile_enable(True)
     c.profile_reset()
     for _ in range(5):
-        c.run_device(d.data_ptr(), 1, S, S)
+        c.submit_device(d.data_ptr(), 1, S, S)
+        c.wait()
     prof = c.profile()
+    c.profile_reset()
+    for _ in range(3):
+        c.run_device(d.data_ptr(), 1, S, S)
+    prof_sync = c.profile()
     for c in ctxs:
         c.close()
     dk = prof["descriptor"]
@@ -668,7 +681,9 @@ def configs4_leg(local_rank, torch):
         "features": n,
         "Mpix_per_s_one_context": round(S * S / lat / 1e6, 1), "ms_per_image_one_context": round(lat * 1e3, 3),
         "Mpix_per_s_three_contexts": round(S * S / dt / 1e6, 1), "ms_per_image_three_contexts": round(dt * 1e3, 3),
+        "Mpix_per_s_five_contexts": round(S * S / dt5 / 1e6, 1), "ms_per_image_five_contexts": round(dt5 * 1e3, 3),
         "kernel_ms_per_image": {k: round(v["ms"] / 5, 4) for k, v in prof.items() if v["launches"]},
+        "descriptor_ms_per_image_synchronous_form": round(prof_sync["descriptor"]["ms"] / 3, 4),
         "roofline_descriptor": {
             "bound": "hbm", "kernel": _desc_kernel_name(int(ctxs[0].params.descriptor_order), mirror) + " (half descriptors)", "achieved": round(fbytes / dur / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / dur / 1e9 / HBM_PEAK_GBS, 4),
