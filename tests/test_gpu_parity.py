@@ -533,3 +533,24 @@ def test_a_submitted_pair_runs_like_a_larger_batch_with_the_same_results(gpu_ctx
         ok, od = o.fetch(b)
         _assert_same_features(ref[b][0], ref[b][1], ok, od, f"pair img {b}")
     o.close()
+
+
+def test_detection_store_spills_beyond_a_scan_tasks_slots(gpu_ctx_factory):
+    """The extrema scan writes every detection into the 64 slots its scan task owns (a wavefront's strip of 124 columns x a
+    segment of rows, all detection levels) and what does not fit into the image's spill list (k_detect.hip, DetectSink);
+    extrema_place_kernel then orders slots and spill list alike.  Dense noise at a low threshold puts several hundred
+    detections into one task: the raw list must still be the oracle's, byte for byte -- for one image (short segments)
+    and for a batch of four (long segments), with and without top-K."""
+    rng = np.random.RandomState(5)
+    imgs = (rng.rand(4, 96, 248) * 255).astype(np.uint8)
+    kw = dict(dog_threshold=0.0004, edge_threshold=60.0)
+    for extra in ({}, dict(truncate_method=_abi.TRUNC_TOPK, feature_count_threshold=700)):
+        g = gpu_ctx_factory(**kw, **extra)
+        o = OracleSession(threads=8, keep_levels=False, **kw, **extra)
+        for batch in (imgs[:1], imgs):
+            _compare_all(g, o, batch, f"dense detections, batch of {len(batch)} {extra}", stages=False)
+            raw = o.rawlist(0)
+            lvl0 = raw[raw["level_index"] < 3]   # octave 0: strips of 124 columns, segments of 12 (one or two images) or 24 rows
+            rows = 12 if len(batch) <= 2 else 24
+            task = (lvl0["col"] // 124) * 1000 + lvl0["row"] // rows
+            assert np.bincount(task).max() > 64 * 2, "the input does not overflow a task's slots: the test would prove nothing"

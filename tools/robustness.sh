@@ -11,7 +11,7 @@ T="tests/test_gpu_parity.py tests/test_reference_inputs_gpu.py tests/test_keypoi
 V1="HESS_DELIVERY=mirror HESS_DELIVERY=blit HESS_DELIVERY=dma HESS_CHAIN_FROM=2 HESS_CHAIN_FROM=99 HESS_NO_PAIR=1 HESS_STREAM_ROWS=12"
 V2="HESS_COPIER=hip HESS_DESC_XCD=0 HESS_DESC_XCD=3 HESS_NO_TOP_FUSION=1 HESS_NO_FIRST_FUSION=1 HESS_NO_PRIME_BATCH=1 HESS_MIRROR_MAX_MB=0 HESS_DESC_PARTS=3"
 case "$PART" in 1) VS="$V1";; 2) VS="$V2";; *) VS="$V1 $V2";; esac
-echo "== $(date -u +%FT%TZ) commit $(git rev-parse --short HEAD 2>/dev/null || cat .commit 2>/dev/null || echo unknown) part $PART" >> $LOG
+echo "== $(date -u +%FT%TZ) kernel sources $(python3 -c 'from hessgpu_amd import build; print(build.sources_digest())' 2>/dev/null || echo unknown) (commit $(git rev-parse --short HEAD 2>/dev/null || echo 'n/a on the GPU box')) part $PART" >> $LOG
 for v in $VS; do
   n=$(echo $v | tr '=' '_')
   env HESS_TEST_DEV_BUILD=1 $v timeout -k 10 500 python -m pytest $T -m gpu -q > $OUT/$n.log 2>&1
