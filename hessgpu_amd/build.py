@@ -32,7 +32,9 @@ DEV_SWITCH_SOURCES = ("hess_abi.hip", "hess_copier.hip", "hess_shared.hip")  # t
 # instructions (v_pk_add/mul/fma_f32), which on gfx950 issue at half rate (tools/micro/README.md) and need
 # extra register moves to form the pairs: without it the descriptor kernel runs 10 % faster (1.37 -> 1.23 ms
 # per 16x1080p step), results bit-identical.  The Gaussian kernel is 3 % faster WITH it, so it stays on there.
-FILE_FLAGS = {"k_feature.hip": ["-fno-slp-vectorize"]}
+# hess_match.hip: MFMA results straight into vector registers (no v_accvgpr_read per accumulator before the folds): matcher
+# + 1.6 % (213 -> 216 TMAC/s at 8192^2, same call, profiles/r06_experiments/matcher.txt).
+FILE_FLAGS = {"k_feature.hip": ["-fno-slp-vectorize"], "hess_match.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources_digest():

@@ -294,8 +294,12 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const uint8_t* des1, in
       const uint8_t* pa = des1 + (size_t)(i0 + 32 * blk + prow) * KD + 16 * h;  // (set 1 is padded to whole workgroups)
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) a[blk][kk] = *reinterpret_cast<const v4i*>(pa + kk * 32) ^ (int)0x80808080;
+      const v4i* const pr = reinterpret_cast<const v4i*>(rfix + i0 + 32 * blk + 16 * h);  // (16 consecutive rows: 64-byte aligned)
 #pragma unroll
-      for (int reg = 0; reg < 16; reg++) ra[blk][reg] = rfix[i0 + 32 * blk + reg + 16 * h];
+      for (int q = 0; q < 4; q++) {
+        const v4i t = pr[q];
+        ra[blk][4 * q] = t.x; ra[blk][4 * q + 1] = t.y; ra[blk][4 * q + 2] = t.z; ra[blk][4 * q + 3] = t.w;
+      }
     }
   }
   int rmx[2][16], rnx[2][16];
@@ -390,21 +394,28 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const uint8_t* des1, in
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) rs[(reg + 16 * h) * MM_RS_PITCH + r] = make_int2(rmx[blk][reg], rnx[blk][reg]);
     __builtin_amdgcn_wave_barrier();  // (one wavefront's LDS operations complete in order)
-    if (lane < 32) {
-      const int2* const row = rs + lane * MM_RS_PITCH;
+    {
+      // lane (row r, half hh) walks the 16 classes 16 hh .. 16 hh + 15 of its row in ascending order ('>' on the score: the
+      // lower class keeps a tie); then the two halves of a row are combined the same way (the lower classes' half wins a tie)
+      const int2* const row = rs + r * MM_RS_PITCH + 16 * h;
       int2 s = row[0];
-      int cls = 0;
-#pragma unroll 8
-      for (int c2 = 1; c2 < 32; c2++) {  // ascending class order, '>' on the score: the lower class keeps a tie
+      int cls = 16 * h;
+#pragma unroll 5
+      for (int c2 = 1; c2 < 16; c2++) {
         const int2 u = row[c2];
         const bool take = (u.x >> 6) > (s.x >> 6);
         s.y = take ? max(s.x, u.y) : max(s.y, u.x);
         s.x = take ? u.x : s.x;
-        cls = take ? c2 : cls;
+        cls = take ? 16 * h + c2 : cls;
       }
+      const int ox = __shfl_xor(s.x, 32), oy = __shfl_xor(s.y, 32), ocls = __shfl_xor(cls, 32);
+      const bool take = (ox >> 6) > (s.x >> 6);   // (meaningful in the lanes of half 0, which store)
+      s.y = take ? max(s.x, oy) : max(s.y, ox);
+      s.x = take ? ox : s.x;
+      cls = take ? ocls : cls;
       const int low = s.x & 63;
-      const int grow = i0 + 32 * blk + lane;
-      if (grow < num1)
+      const int grow = i0 + 32 * blk + r;
+      if (h == 0 && grow < num1)
         rstate[(size_t)grow * nseg + sg] = make_int3(s.x >> 6, s.y >> 6, low == 63 ? -1 : (s0 * 4 + 62 - low) * 32 + cls);
     }
     __builtin_amdgcn_wave_barrier();
