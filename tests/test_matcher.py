@@ -166,3 +166,30 @@ def test_siftmatchgpu_class_through_the_c_mirror():
     n = L.siftmatch_get_match(h, 4096, buf.ctypes.data, 0.7, 0.8, 1)
     assert np.array_equal(buf[:n], oracle_match(oracle_quantize(f1), oracle_quantize(f2)))
     L.siftmatch_destroy(h)
+
+
+@pytest.mark.gpu
+def test_matrix_core_path_is_the_same_every_time():
+    """The unguided match is the same every time: 300 matches of each size (ragged against the 256-row / 128-column blocks,
+    one far wider than tall), mutual best and not, every one equal to the first, which equals the oracle's.  (Written for a
+    form that finished inside the multiply launch -- the workgroup that happened to finish last merged what the others wrote --
+    which was correct and 60 % slower, profiles/r06_experiments/matcher.txt; the test is what stays.)"""
+    from hessgpu_amd.matcher import Matcher
+    from oracle_lib import oracle_match
+
+    rng = np.random.RandomState(11)
+    for n1, n2 in ((2049, 2081), (4100, 5000), (300, 33000)):
+        a = rng.randint(0, 256, size=(n1, 128)).astype(np.uint8)
+        b = rng.randint(0, 256, size=(n2, 128)).astype(np.uint8)
+        b[7] = a[2]; b[n2 - 2] = a[2]; a[n1 - 1] = a[2]; b[n2 // 2] = b[3]
+        m = Matcher(0, max_sift=max(n1, n2))
+        m.set_descriptors(0, a)
+        m.set_descriptors(1, b)
+        for mutual in (True, False):
+            first = m.match(max_match=max(n1, n2), mutual_best=mutual)
+            if n1 * n2 < 12_000_000:
+                assert np.array_equal(first, oracle_match(a, b, max_match=max(n1, n2), mutual_best=mutual))
+            for k in range(300):
+                again = m.match(max_match=max(n1, n2), mutual_best=mutual)
+                assert np.array_equal(again, first), (n1, n2, mutual, k)
+        m.close()
