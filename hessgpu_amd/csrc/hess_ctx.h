@@ -65,6 +65,7 @@ struct EventPair {
   double bytes;
   int kernel2 = -1;  // a second accumulator for the same launch (HESS_K_GAUSS_OCT0), or -1
   double in_lds = 0.0;  // bytes of the reference's array layout this launch neither writes nor reads: the array lives in LDS only
+  int count = 1;     // launches between the two events (ProfRun: a run of consecutive launches of one kernel family)
 };
 
 

@@ -1,4 +1,6 @@
 // hess_schedule.hip -- the launch order of one batch on the context's stream (see hess_ctx.h).
+#include <optional>
+
 #include "hess_ctx.h"
 
 namespace hess {
@@ -31,16 +33,48 @@ struct ProfScope {
     c->pending.push_back(ep);
   }
 };
+// A RUN of consecutive launches of one kernel family between ONE pair of events: an event record between two kernels leaves
+// the stream idle for a few microseconds, which per-launch pairs book on 22 pyramid launches a step (the hipEvent figure of
+// the Gaussian stage read 0.53 ms where the kernel trace sums 0.47).  The launches of octave 0 keep a pair each (their
+// share of the stage is reported apart); the small octaves' launches, which follow them back to back, share one.
+struct ProfRun {
+  hess_ctx* c;
+  int kernel;
+  EventPair ep;
+  bool open = false;
+  ProfRun(hess_ctx* ctx, int k) : c(ctx), kernel(k) {}
+  void add(double bytes, double in_lds = 0.0) {
+    if (!c->prof) return;
+    if (!open) {
+      ep = EventPair{};
+      ep.a = get_event(c); ep.b = get_event(c); ep.kernel = kernel; ep.bytes = 0.0; ep.count = 0;
+      if (!ep.a || !ep.b || hipEventRecord(ep.a, c->st) != hipSuccess) {
+        if (ep.a) c->pool.push_back(ep.a);
+        if (ep.b) c->pool.push_back(ep.b);
+        return;
+      }
+      open = true;
+    }
+    ep.bytes += bytes; ep.in_lds += in_lds; ep.count++;
+  }
+  void close() {
+    if (!open) return;
+    open = false;
+    if (hipEventRecord(ep.b, c->st) != hipSuccess) { c->pool.push_back(ep.a); c->pool.push_back(ep.b); return; }
+    c->pending.push_back(ep);
+  }
+  ~ProfRun() { close(); }
+};
 void drain_profile(hess_ctx* c) {
   for (auto& ep : c->pending) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
       c->k_ms[ep.kernel] += ms;
-      c->k_n[ep.kernel] += 1;
+      c->k_n[ep.kernel] += ep.count;
       c->k_bytes[ep.kernel] += ep.bytes;
       c->k_in_lds[ep.kernel] += ep.in_lds;
       if (ep.kernel2 >= 0) {
-        c->k_ms[ep.kernel2] += ms; c->k_n[ep.kernel2] += 1; c->k_bytes[ep.kernel2] += ep.bytes; c->k_in_lds[ep.kernel2] += ep.in_lds;
+        c->k_ms[ep.kernel2] += ms; c->k_n[ep.kernel2] += ep.count; c->k_bytes[ep.kernel2] += ep.bytes; c->k_in_lds[ep.kernel2] += ep.in_lds;
       }
     }
     c->pool.push_back(ep.a);
@@ -175,6 +209,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
     if (chain_from > g.noct) chain_from = g.noct;
   }
   const bool chained = chain_from < g.noct;
+  ProfRun small_octaves(c, HESS_K_GAUSS);  // one event pair for the consecutive launches of octaves >= 1 (see ProfRun)
   GaussJob top_jobs[kMaxOct];  // the top levels of the octaves that do not ride with the next octave's level 1
   int ntop = 0;
   double top_bytes = 0.0, top_in_lds = 0.0;
@@ -196,7 +231,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
       cj.decim_dst = decim ? plane_ptr(gauss, o + 1, 0) : nullptr;
       cj.decim_w = decim ? g.o[o + 1].wa : 0; cj.decim_h = decim ? g.o[o + 1].h : 0;
       {
-        ProfScope ps(c, HESS_K_GAUSS, bytes);
+        small_octaves.add(bytes);
         if (!launch_gauss_chain(st, cj, batch)) { set_err(c, "level-chain launch refused"); return HESS_ERR_DEVICE; }
       }
       top_jobs[ntop++] = level_job(o, s.level_max);
@@ -238,8 +273,13 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         const int top_o = deferred_o;
         {
           const GaussJob ja = level_job(top_o, s.level_max), jb = level_job(o, 1);
-          ProfScope ps(c, HESS_K_GAUSS, level_bytes(top_o, s.level_max) + level_bytes(o, 1), top_o == 0 ? HESS_K_GAUSS_OCT0 : -1,
-                       level_in_lds(top_o, s.level_max));
+          std::optional<ProfScope> ps;
+          if (top_o == 0) {
+            small_octaves.close();
+            ps.emplace(c, HESS_K_GAUSS, level_bytes(top_o, s.level_max) + level_bytes(o, 1), HESS_K_GAUSS_OCT0, level_in_lds(top_o, s.level_max));
+          } else {
+            small_octaves.add(level_bytes(top_o, s.level_max) + level_bytes(o, 1), level_in_lds(top_o, s.level_max));
+          }
           if (launch_gauss_pair(st, ja, jb, batch)) c->zero_filled = c->zero_filled || ja.zero != nullptr;
           else { launch_level(ja); launch_level(jb); }
         }
@@ -253,16 +293,18 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         continue;
       }
       if (l == s.level_max && pair_levels && o + 1 < g.noct) { deferred_o = o; continue; }
-      ProfScope ps(c, HESS_K_GAUSS, level_bytes(o, l), o == 0 ? HESS_K_GAUSS_OCT0 : -1, level_in_lds(o, l));
+      std::optional<ProfScope> ps;
+      if (o == 0) { small_octaves.close(); ps.emplace(c, HESS_K_GAUSS, level_bytes(o, l), HESS_K_GAUSS_OCT0, level_in_lds(o, l)); }
+      else small_octaves.add(level_bytes(o, l), level_in_lds(o, l));
       launch_level(level_job(o, l));
     }
   }
   if (deferred_o >= 0) {  // (cannot happen: the last octave never defers)
-    ProfScope ps(c, HESS_K_GAUSS, level_bytes(deferred_o, s.level_max), -1, level_in_lds(deferred_o, s.level_max));
+    small_octaves.add(level_bytes(deferred_o, s.level_max), level_in_lds(deferred_o, s.level_max));
     launch_level(level_job(deferred_o, s.level_max));
   }
   if (ntop) {  // the top levels left over by the chain, one launch
-    ProfScope ps(c, HESS_K_GAUSS, top_bytes, -1, top_in_lds);
+    small_octaves.add(top_bytes, top_in_lds);
     // (+ det-H / gradient of levels 0..level_ds-1 of the chain-launched octaves, from HBM: hessian_low_levels)
     LowLevels low{&g, gauss, deth, got, s.norm, chain_from, chained ? s.level_ds : 0};
     if (launch_gauss_multi(st, top_jobs, ntop, batch, &low)) {
@@ -273,6 +315,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
         for (int o = chain_from; o < g.noct; o++) launch_hessian(st, g, o, gauss, deth, got, s.norm, batch, 0, s.level_ds - 1);
     }
   }
+  small_octaves.close();
   if (c->stage_events) HIP_TRY(c, hipEventRecord(c->ev[1], st));
   // ---- det-Hessian + gradient (DetectKeypointsEX part 1, PyramidCU.cpp:1576-1591) ----
   // (levels 0 .. level_max-1: by the launch that reads the level as its source; the top level: by the launch that
