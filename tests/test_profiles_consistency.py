@@ -58,3 +58,34 @@ def test_kernel_stats_top_is_the_top_row_of_the_committed_table():
 def test_chip_constants_used_by_the_bench_line():
     assert 800.0 < _j("valu_peak.json")["sustained_fma_ginst_all_cus"] <= 1228.8
     assert 3000.0 < _j("hbm_mix.json")["one_read_four_writes_gbs"] < 8000.0
+
+
+def test_committed_summaries_say_what_they_were_measured_on_and_bench_drops_stale_ones(monkeypatch):
+    """Every kernel-profile summary bench.py copies numbers from records the hash of the kernel sources it was measured on
+    (hessgpu_amd/build.py sources_digest()) and the commit; bench.py's reader marks one measured on OTHER sources as stale and
+    hands out none of its numbers (round 5: an intermediate run multiplied a committed instruction count by a new kernel's
+    time and printed a fraction of 1.10)."""
+    import importlib.util
+    import sys
+
+    for name in ("gauss_traffic.json", "descriptor_counters.json", "kernel_stats_top.json"):
+        d = _j(name)
+        assert re.fullmatch(r"[0-9a-f]{16}", d["kernel_sources_sha16"]) and d["commit"], name
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from hessgpu_amd import build
+
+    assert re.fullmatch(r"[0-9a-f]{16}", build.sources_digest())
+    # as committed: current or stale, but consistently so
+    d = bench._profile_json("descriptor_counters.json")
+    stale = bool(d.get("stale"))
+    assert (bench._profile_value("descriptor_counters.json", "valu_insts_per_feature") is None) == stale
+    # a summary of other sources: stale, no numbers
+    bench._sources_sha16[:] = ["0" * 16]
+    d = bench._profile_json("descriptor_counters.json")
+    assert d["stale"] is True and "0000000000000000" in d["stale_reason"]
+    assert bench._profile_value("descriptor_counters.json", "valu_insts_per_feature") is None
+    # chip constants carry no source hash: always used
+    assert bench._profile_value("valu_peak.json", "sustained_fma_ginst_all_cus") > 0
