@@ -184,4 +184,6 @@ def test_one_rank_through_the_launcher_agrees_with_the_plain_run():
             assert "RCCL" in d["config"]["sharding"] and d["config"]["exchange"].startswith("helper thread")
     plain, spawn = max(vals["plain"], vals["plain2"]), max(vals["spawn"], vals["spawn2"])
     # (the dist path uses 6 contexts like the plain run here: FORCE_DIST keeps world == 1)
-    assert abs(spawn - plain) / plain < 0.05, vals
+    # (best of two each; identical runs on one box differ by up to 7 % -- the same-call A/B lines under profiles/ -- so this
+    # bounds a systematic cost of the N > 1 path, it does not resolve 2 %: measured 0 - 3 %)
+    assert spawn > 0.92 * plain, vals
