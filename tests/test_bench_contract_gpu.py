@@ -163,7 +163,7 @@ def test_a_rank_that_dies_mid_run_ends_the_self_launched_job():
                         "--contexts", "2", "--batch", "2", "--no-profile", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
                        env=_bare_env(HESS_BENCH_BACKEND="gloo", HESS_BENCH_SAME_GPU="1", HESS_BENCH_TEST_EXIT="1:2:17"))
     assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
-    assert "rank(s) ended non-zero [(1, 17)]" in r.stderr
+    assert "rank(s) ended non-zero" in r.stderr and "(1, 17)" in r.stderr   # (rank 0 may fail on the broken connection in the same poll)
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]      # no result line from a broken job
     assert time.monotonic() - t0 < 300
 
