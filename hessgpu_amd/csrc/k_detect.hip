@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void hessian_kernel(HessArgs a) {
 __global__ __launch_bounds__(256) void hessian_rows4_kernel(Geom g, const float* gauss, float* deth, int level, float norm,
                                                             uint4* zero, long long zero_n) {
   // On the side: clear what the detection stages expect zeroed (overflow words, row counts, top-K histogram, extrema
-  // masks: one allocation, hess_pipeline.hip) -- a grid-stride fill by this launch's threads instead of a fill
+  // masks: one allocation, hess_plan.hip) -- a grid-stride fill by this launch's threads instead of a fill
   // launch of its own in the dependent chain.
   if (zero) {
     const long long nthr = (long long)gridDim.x * gridDim.y * 256;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams
 //   4. one workgroup scan gives every thread its tie rank and output position -- of the first T ties min(T, need) are
 //      kept -- and the kept entries are copied in list order; the last chunk in use posts the kept total.
 // Same result as before: the K largest abs(half(response)), ties at the cut to the lower list index, list order kept.
-// ticket / state / sel_level_count arrive zeroed (they live in the batch's cleared block, hess_pipeline.hip).
+// ticket / state / sel_level_count arrive zeroed (they live in the batch's cleared block, hess_plan.hip).
 constexpr int TK_PER = 4, TK_CHUNK = 1024 * TK_PER;
 
 
@@ -1121,7 +1121,7 @@ int extrema_tasks(const Geom& g) { return extrema_streams(g) ? g.nstream * 4 : g
 
 void launch_extrema_mark(hipStream_t st, const Geom& g, const DetectParams& dp, const float* gauss,
                          const float* deth, uint64_t* rowmask, int* rowcnt, const DetectStore& ds, int batch) {
-  // rowcnt, rowmask, ds.spill_count and ds.hist arrive zeroed (one fill per batch in enqueue(), hess_pipeline.hip)
+  // rowcnt, rowmask, ds.spill_count and ds.hist arrive zeroed (one fill per batch in enqueue(), hess_schedule.hip)
   // streaming scan; its candidate queue packs row and column in 14 bits each
   if (extrema_streams(g)) {
     unsigned long long* rm = reinterpret_cast<unsigned long long*>(rowmask);

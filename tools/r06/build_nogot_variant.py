@@ -17,15 +17,18 @@ dst = os.path.join(tmp, "hessgpu_amd", "csrc")
 os.makedirs(os.path.dirname(dst))
 shutil.copytree(build.CSRC, dst, ignore=shutil.ignore_patterns("_obj"))
 shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
-p = os.path.join(dst, "hess_pipeline.hip")
+p = os.path.join(dst, "hess_schedule.hip")
 s = open(p).read()
 old = "    j.norm_src = s.norm[l - 1];\n"
-new = "    { static thread_local int xb = 0; if (o == 0 && l == 1) xb++; }\n    if (c->x_batches > 2) j.got_src = nullptr;\n    j.norm_src = s.norm[l - 1];\n"
+new = "    if (c->x_batches > 2) j.got_src = nullptr;\n    j.norm_src = s.norm[l - 1];\n"
 assert old in s
 s = s.replace(old, new, 1)
 old = "  c->stage_events = (c->p.verbose & 2) != 0;\n"
 assert old in s
 s = s.replace(old, old + "  c->x_batches++;\n", 1)
+open(p, "w").write(s)
+p = os.path.join(dst, "hess_ctx.h")
+s = open(p).read()
 old = "  int regrown = 0;"
 assert old in s
 s = s.replace(old, "  int x_batches = 0;\n  int regrown = 0;", 1)
