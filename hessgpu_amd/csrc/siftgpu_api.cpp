@@ -74,7 +74,10 @@ struct Impl {
   // of list entries i + 1 .. i + kAhead are read and decoded on host threads (`ahead`: list index -> decode in flight),
   // so that a caller walking the list -- hess -il (hessgpucmd.cpp:61-89), speed -- waits for the device, not for a
   // single-threaded JPEG decode.  list_index: the list entry the current _imgpath came from (-1: not from the list).
-  static constexpr int kAhead = 4;
+  // Twelve entries ahead, not four: a list of mixed sizes needs LEAD TIME, not only threads -- a 2048 x 1536 JPEG decodes in
+  // 25 ms, thirty times what an image of the list takes to run, so with four entries of lead the walk stalled 20 ms at
+  // every large file (2.7 ms per image over the reference's data/ mix; profiles/r06_experiments/list_callers.txt).
+  static constexpr int kAhead = 12;
   int list_index = -1;
   std::map<int, std::future<DecodedImage>> ahead;
 };
@@ -857,10 +860,26 @@ void SiftGPU::SaveSIFT(const char* szFileName) {  // SiftPyramid::SaveSIFT, Sift
       out << " " << std::setprecision(8) << pk->response;
       out << " " << pk->type << " " << pk->level;
       out << std::endl;
-      if (dim) {
+      if (dim && im->p.normalize) {
+        // the 128 integers of a descriptor: decimal digits written by hand (the stream's integer formatting of half a
+        // million numbers per 1080p image took 4 ms; the characters are the same: an unsigned value, one blank, a
+        // newline after every 20th)
+        char line[128 * 12 + 16];
+        char* q = line;
         for (int k = 0; k < dim; k++, pd++) {
-          if (im->p.normalize) out << ((unsigned int)floor(0.5 + 512.0f * (*pd))) << " ";
-          else out << std::setprecision(8) << pd[0] << " ";
+          unsigned int v = (unsigned int)floor(0.5 + 512.0f * (*pd));
+          char digits[12];
+          int nd = 0;
+          do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+          while (nd) *q++ = digits[--nd];
+          *q++ = ' ';
+          if ((k + 1) % 20 == 0) *q++ = '\n';
+        }
+        *q++ = '\n';
+        out.write(line, q - line);
+      } else if (dim) {
+        for (int k = 0; k < dim; k++, pd++) {
+          out << std::setprecision(8) << pd[0] << " ";
           if ((k + 1) % 20 == 0) out << std::endl;
         }
         out << std::endl;
