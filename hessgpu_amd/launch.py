@@ -39,12 +39,16 @@ def free_port(addr="127.0.0.1"):
         s.close()
 
 
+try:   # (loaded in the parent: the child between fork and exec then only makes the one system call)
+    _LIBC = ctypes.CDLL(None, use_errno=True)
+except Exception:
+    _LIBC = None
+
+
 def _child_setup():
-    # (runs in the child between fork and exec: async-signal-safe enough -- one setsid done by Popen, one prctl)
-    try:
-        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)   # PR_SET_PDEATHSIG
-    except Exception:
-        pass
+    # runs in the child between fork and exec (Popen has done setsid): have the kernel end this rank if the launcher dies
+    if _LIBC is not None:
+        _LIBC.prctl(1, int(signal.SIGKILL), 0, 0, 0)   # PR_SET_PDEATHSIG
 
 
 def rank_env(rank, world, port, base=None, addr="127.0.0.1"):
