@@ -77,6 +77,7 @@ hess_ctx* hess_create(int device, const hess_params* params) {
   c->no_host_upload = dev_env("HESS_NO_SIDE_UPLOAD") != nullptr;
   if (const char* dpn = dev_env("HESS_DESC_PARTS")) c->desc_parts = atoi(dpn);
   if (const char* sr = dev_env("HESS_STREAM_ROWS")) c->stream_rows = atoi(sr) > 0 ? (atoi(sr) / 3) * 3 : 0;
+  if (const char* pb = dev_env("HESS_PX_BAND")) c->desc_px_band = std::min(4096, std::max(64, atoi(pb)));
   if (const char* dx = dev_env("HESS_DESC_XCD")) c->desc_xcd_block = atoi(dx) > 0 ? atoi(dx) : 0;
   return c;
 }

@@ -261,6 +261,7 @@ struct hess_ctx {
   bool no_host_upload = false;     // HESS_NO_SIDE_UPLOAD: pinned input is uploaded by a copy on the context's stream (A/B switch)
   int desc_parts = 0;              // HESS_DESC_PARTS: descriptor launches / result transfers per batch (0: default)
   int stream_rows = 0;             // HESS_STREAM_ROWS: rows per wavefront segment of the extrema scan (0: by batch size; A/B switch)
+  int desc_px_band = 4096;         // HESS_PX_BAND: pixels per raster band of descriptor_pixel_kernel (test hook: small bands at ordinary footprints)
   int desc_xcd_block = 64;         // HESS_DESC_XCD: features per XCD block of the descriptor launch (0: plain order; A/B switch)
   Copier cp;
   Stager sg;

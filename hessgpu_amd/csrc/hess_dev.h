@@ -137,6 +137,7 @@ struct DescParams {
   int xcd_block;         // features per block of the list handed to one XCD's workgroups (0: plain order)
   int sequential;        // HESS_DESC_ORDER_SEQUENTIAL: bins summed in the reference's sample order (else four interleaved partial sums)
   int pixel;             // HESS_DESC_ORDER_PIXEL: one raster over the footprint, fixed-point sums (descriptor_pixel_kernel); wins over `sequential`
+  int px_band;           // pixel raster: pixels per band of rows, 64 .. 4096 (4096 unless HESS_PX_BAND of the developer build says otherwise)
   int part, part_den;    // part_den > 1 (one image per launch): the launch does features [n part / part_den, n (part + 1) / part_den) of the image's n
 };
 

@@ -416,6 +416,7 @@ int enqueue(hess_ctx* c, const void* dev, int pitch, size_t image_stride, int ba
   dsp.first_image = 0;
   dsp.part = 0; dsp.part_den = 1;
   dsp.xcd_block = c->desc_xcd_block;
+  dsp.px_band = c->desc_px_band;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   // the pixel order's fixed point assumes luminance in [0, 1] (8- and 16-bit inputs); float pixels are taken as they are
   // and keep the interleaved order (the test oracle applies the same rule)
@@ -568,6 +569,7 @@ int enqueue_user(hess_ctx* c) {
   dsp.first_image = 0;
   dsp.part = 0; dsp.part_den = 1;
   dsp.xcd_block = c->desc_xcd_block;
+  dsp.px_band = c->desc_px_band;
   dsp.sequential = p.descriptor_order == HESS_DESC_ORDER_SEQUENTIAL;
   dsp.pixel = 0;  // a keypoint list is described in a floating-point order (interleaved unless the sequential one is asked for)
   c->nparts = 1;

@@ -860,7 +860,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 // ================================= descriptor, pixel raster ===================================
 //
 // HESS_DESC_ORDER_PIXEL (include/hess_abi.h; restated by the test oracle, compute_descriptor_pixel): one wavefront
-// per feature rasters the bounding box of the rotated 5 x 5-cell footprint ONCE, 64 pixels per step, one per lane.
+// per feature rasters the rotated 5 x 5-cell footprint ONCE, 64 pixels per step, one per lane (the pixels of the
+// footprint's rows inside its bounding box: "row spans" in the kernel).
 // In the keypoint frame (u, v) = R(-angle)(pixel - keypoint) / spt everything the reference recomputes per (pixel,
 // cell) pair is a per-pixel quantity -- the gather, the Gaussian weight exp(-(u^2 + v^2)/8), the bin coordinate theta
 // and its split, and the bilinear cell weights (the split of u + 1.5, v + 1.5 between the two nearest cell indices) --
@@ -889,6 +890,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 constexpr int PX_COPIES = HESS_PX_COPIES;  // (A/B builds: -DHESS_PX_COPIES=2|8, -DHESS_PX_UNROLL=1|3; same call, descriptor ms per step of 8: 2 copies 0.230, 4: 0.226, 8: 0.269 -- with eight the LDS footprint holds the kernel at four wavefronts per SIMD -- 16: 0.50)
 constexpr int PX_COPY_U64 = 128 + 4;
 constexpr int PX_WAVE_U64 = PX_COPIES * PX_COPY_U64;
+constexpr float PX_SPAN_EPS = 0.02f;
+constexpr int PX_BAND_MAX = 4096;  // pixels of a raster band (dp.px_band) at most: 64 steps, one word of row-start bits per lane
 
 // N consecutive steps of a lane: keypoint-frame coordinates (u = 3 marks a step outside the window or past the box),
 // gathered (gradient, theta)
@@ -901,8 +904,10 @@ struct PixChunk {
 
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
+// (amdgpu_waves_per_eu(7, 7): 23 040 bytes of LDS per workgroup admit seven workgroups per CU; left alone the register
+// allocator takes 77 registers = six wavefronts per SIMD.  71 registers, nothing spilled, launch 86.6 -> 85.1 us.)
 template <bool HOST_MIRROR>
-__global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
                                                                int cap_list, const FRec* recs,
                                                                const int* fsrc, const int* feat_total,
                                                                const int* feat_first, const int* img_base,
@@ -910,6 +915,7 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
                                                                int cap_feat) {
   __shared__ __attribute__((aligned(16))) float dl[4][128];
   __shared__ __attribute__((aligned(16))) unsigned long long hist[4][PX_WAVE_U64];
+  __shared__ __attribute__((aligned(16))) uint4 rowtab[4][64];  // per wavefront: the rows of the current raster band
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y + dp.first_image;
   int ftotal = feat_total[b], ffirst = feat_first[b];
@@ -980,37 +986,87 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
     // (the same in every lane: the box is the feature's)
     const int nxs = __builtin_amdgcn_readfirstlane((xmax >= xmin) ? (int)(xmax - xmin) + 1 : 0);
     const int nys = __builtin_amdgcn_readfirstlane((ymax >= ymin) ? (int)(ymax - ymin) + 1 : 0);
-    const int total = nxs * nys;
-    const int nit = (total + 63) >> 6;
-    // Lane's pixel of step `it`: t = 64 it + lane -> (t % nxs, t / nxs).  Start by one exact division, then 64 places
-    // along the raster per step by exact float increments: 64 = a nxs + r, so x += r (and back by a row's length
-    // when that passes xmax), y += a (+ 1) -- integers + 0.5 far below 2^23.
-    const float inv = 1.0f / (float)(nxs > 0 ? nxs : 1);
-    const int a64 = (int)((64.0f + 0.5f) * inv), r64 = 64 - a64 * nxs;  // (exact: |error| << 0.5/nxs)
-    const int sy0 = (int)(((float)lane + 0.5f) * inv), sx0 = lane - __mul24(sy0, nxs);
-    float xf = xmin + (float)sx0;
-    float yf = (total > 0) ? ymin + (float)sy0 : 3.0e38f;
-    unsigned goff = (unsigned)(((int)ymin + sy0) * width + (int)xmin + sx0) * 8u;
-    const float fr64 = (float)r64, fa64 = (float)a64, fnxs = (float)nxs;
-    const unsigned gstep = (unsigned)(a64 * width + r64) * 8u, gwrap = (unsigned)(width - nxs) * 8u;
+    // Row spans.  The window |u| < 2.5, |v| < 2.5 is a rotated square: of the box's pixels 1 / (|c| + |s|)^2 lie inside
+    // (0.61 on average over the angles), so the raster runs over the window's own rows instead: row y of the box keeps
+    // the pixels x_lo(y) .. x_hi(y), the real-arithmetic solution of the two inequalities for x, slightly widened (a
+    // SUPERSET of the pixels that pass the test: every pixel is still tested with the floats the oracle uses, so which
+    // pixels count does not depend on the spans; integer sums do not depend on the order either).
+    // Bands of <= 64 rows (lane = row) and <= dp.px_band pixels: prefix sums of the span lengths give every row its first
+    // place S in the band's sequence; a 64-bit word per step holds the places where rows start (bit S mod 64 of word
+    // S / 64, lane w keeps word w), so the lane of place t = 64 step + lane finds its row with two mbcnt and reads the
+    // row's entry (first pixel's index - S, x - S, y) from LDS.
+    // (a coefficient below 1e-3 per pixel: that inequality is left out -- it cuts the corners of the box only -- so that the
+    // rounding of u, v, 1e-6 at most, stays below 1e-3 pixel in x; the spans are widened by PX_SPAN_EPS = 0.02)
+    const float rA = (fabsf(crspt) > 1.0e-3f) ? 1.0f / crspt : 0.0f, rB = (fabsf(srspt) > 1.0e-3f) ? 1.0f / srspt : 0.0f;
+    const int px_band = __builtin_amdgcn_readfirstlane(dp.px_band);
+    for (int ib = 0; ib < nxs; ib += px_band) {  // (column bands: a box wider than a band -- no detected feature's is)
+    const int ncol = min(nxs - ib, px_band);
+    const int band_rows = min(64, px_band / ncol);
+    for (int jb = 0; jb < nys; jb += band_rows) {
+    const int nrow = min(band_rows, nys - jb);
+    int T;
+    uint32_t mword_lo, mword_hi;
+    {
+      const float yrow = ymin + (float)(jb + lane), dyr = yrow - ky;
+      float lo = -3.0e38f, hi = 3.0e38f;
+      if (rA != 0.0f) {  // |crspt dx + srspt dy| < 2.5
+        const float t1 = (-2.5f - srspt * dyr) * rA, t2 = (2.5f - srspt * dyr) * rA;
+        lo = fminf(t1, t2); hi = fmaxf(t1, t2);
+      }
+      if (rB != 0.0f) {  // |crspt dy - srspt dx| < 2.5
+        const float t1 = (crspt * dyr - 2.5f) * rB, t2 = (crspt * dyr + 2.5f) * rB;
+        lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2));
+      }
+      const float off = kx - xmin;  // pixel i of the row: x = xmin + i, dx = i - off
+      const float flo = fmaxf(ceilf(lo + off - PX_SPAN_EPS), (float)ib), fhi = fminf(floorf(hi + off + PX_SPAN_EPS), (float)(ib + ncol - 1));
+      const int len = (lane < nrow && fhi >= flo) ? (int)(fhi - flo) + 1 : 0;
+      const int ilo = (int)flo;
+      const int incl = wave_inclusive_scan(len);
+      const int S = incl - len;
+      T = __builtin_amdgcn_readlane(incl, 63);
+      const uint64_t ne = __builtin_amdgcn_ballot_w64(len > 0);
+      const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
+      unsigned long long* const starts = reinterpret_cast<unsigned long long*>(&dl[wv][0]);
+      starts[lane] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (len > 0) {
+        (void)__hip_atomic_fetch_or(starts + (S >> 6), 1ull << (S & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        rowtab[wv][r] = make_uint4((uint32_t)(((int)ymin + jb + lane) * width + (int)xmin + ilo - S),
+                                   __float_as_uint(xmin + (float)(ilo - S)), __float_as_uint(yrow), 0u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const unsigned long long mw = starts[lane];
+      mword_lo = (uint32_t)mw; mword_hi = (uint32_t)(mw >> 32);
+    }
+    const int nit = (T + 63) >> 6;
+    int step = 0, rows_before = -1;  // (rows that started before this step's 64 places) - 1
+    int tl = lane;
+    float tf = (float)lane;
 
-    // stage A: keypoint-frame coordinates, window test and gather of N steps, issued back to back
+    // stage A: the lane's pixel of N steps (row by the start bits, place in the row), keypoint-frame coordinates, window
+    // test and gather, issued back to back
     auto stage_a = [&](auto& ck) {
       constexpr int N = std::remove_reference_t<decltype(ck)>::N;
 #pragma unroll
       for (int q = 0; q < N; q++) {
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mword_lo, step), mhi = (uint32_t)__builtin_amdgcn_readlane((int)mword_hi, step);
+        const uint64_t m64 = ((uint64_t)mhi << 32) | mlo;
+        int rr = rows_before + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (__builtin_amdgcn_inverse_ballot_w64(m64) ? 1 : 0);
+        rows_before += __builtin_popcountll(m64);
+        rr = (int)min((unsigned)rr, 63u);  // (steps past the band's end: any entry, the lane is switched off below)
+        const uint4 e = rowtab[wv][rr];
+        const float xf = __uint_as_float(e.y) + tf, yf = __uint_as_float(e.z);
+        const unsigned goff = (e.x + (unsigned)tl) * 8u;
         const float dx = xf - kx, dy = yf - ky;
         const float u = fmaf(crspt, dx, srspt * dy);
         ck.v[q] = fmaf(crspt, dy, -(srspt * dx));
-        const bool in = (yf <= ymax) & (fabsf(u) < 2.5f) & (fabsf(ck.v[q]) < 2.5f);
-        ck.u[q] = in ? u : 3.0f;  // (outside the window: steps past the end of the box fail yf <= ymax)
+        const bool in = (tl < T) & (fabsf(u) < 2.5f) & (fabsf(ck.v[q]) < 2.5f);
+        ck.u[q] = in ? u : 3.0f;  // (outside the window)
         const dfloat2 gv = __builtin_amdgcn_raw_buffer_load_b64(grsrc, (int)(in ? goff : 0u), 0, 0);
         ck.cc[q] = make_float2(gv.x, gv.y);
-        xf += fr64;
-        const bool wrap = xf > xmax;
-        xf -= wrap ? fnxs : 0.0f;
-        yf += wrap ? fa64 + 1.0f : fa64;
-        goff += wrap ? gstep + gwrap : gstep;
+        tl += 64; tf += 64.0f; step++;
       }
     };
     // stage B: the pixel's weight, bin and cell split; four 64-bit additions of two fixed-point values each.
@@ -1066,6 +1122,8 @@ __global__ __launch_bounds__(256) void descriptor_pixel_kernel(Geom g, DescParam
         stage_b(cb);
       }
     }
+    }  // row bands
+    }  // column bands
     // The copies' sums: lane (cell, q) reads words 2q, 2q+1 of its cell in every copy (one 16-byte read each), adds the
     // four 32-bit halves apart and clears the words for the next feature.  It owns bins 2q, 2q+1:
     //   bin 2q   = low half of word 2q   + high half of word 2q-1 (lane q-1 of the quad, q = 0: word 7, lane q = 3)
@@ -1148,6 +1206,7 @@ void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, cons
   if (blocks < 1) blocks = 1;
   const int lds_pad = DC_LDS_PAD_BYTES;
   DescParams dpx = dp;
+  dpx.px_band = std::min(PX_BAND_MAX, std::max(64, dp.px_band > 0 ? dp.px_band : PX_BAND_MAX));
   // the block order needs whole blocks per XCD, and a grid of whole rounds over the eight XCDs (else the map from
   // (XCD, wavefront in the XCD) to list blocks is not onto: features would be skipped and others computed twice)
   if (dpx.xcd_block && ((blocks * 4) % (8 * dpx.xcd_block) != 0 || blocks % 8 != 0)) dpx.xcd_block = 0;

@@ -303,6 +303,26 @@ def test_parity_noise_ragged(gpu_ctx_factory, w, h):
     _compare_all(g, o, img, f"noise {w}x{h}")
 
 
+@pytest.mark.parametrize("band", [64, 200, 1000])
+def test_descriptor_raster_bands(gpu_ctx_factory, monkeypatch, band):
+    """descriptor_pixel_kernel rasters a footprint over the row spans of the rotated window, in bands of <= 64 rows and
+    <= 4096 pixels (k_feature.hip).  No detected feature is larger than two bands of rows, so HESS_PX_BAND (developer
+    build) shrinks the band: 64 pixels = one row per band and, for boxes wider than 64, bands of columns too; 200 and
+    1000 = a few rows per band.  The fixed-point sums do not depend on the order: the bits stay the oracle's -- for
+    footprints at every angle (photograph), clipped by the image's border (small image) and for -half."""
+    monkeypatch.setenv("HESS_PX_BAND", str(band))
+    g = gpu_ctx_factory(dev_switches=True)
+    gh = gpu_ctx_factory(dev_switches=True, half_sift=1, first_octave=-1)
+    monkeypatch.delenv("HESS_PX_BAND")
+    o = OracleSession(threads=8, keep_levels=False)
+    oh = OracleSession(threads=8, keep_levels=False, half_sift=1, first_octave=-1)
+    img = fixtures.load_rgb("640-1.jpg")
+    n = _compare_all(g, o, img[None], f"raster bands of {band} pixels", stages=False)
+    assert n[0] > 100
+    small = fixtures.synthetic_blobs(96, 80, 5)
+    _compare_all(gh, oh, small[None], f"raster bands of {band} pixels, upsampled small image, -half", stages=False)
+
+
 @pytest.mark.parametrize("mode", ["mirror", "dma", "blit"])
 def test_result_delivery_modes(gpu_ctx_factory, monkeypatch, mode):
     """Three ways for the results to reach the host (hess_copier.hip, kDeliver*): stores of the descriptor kernel

@@ -9,7 +9,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 LOG=$OUT/robust_log.txt
 T="tests/test_gpu_parity.py tests/test_reference_inputs_gpu.py tests/test_keypoint_list_gpu.py tests/test_descriptor_order.py tests/test_shared_results.py"
 V1="HESS_DELIVERY=mirror HESS_DELIVERY=blit HESS_DELIVERY=dma HESS_CHAIN_FROM=2 HESS_CHAIN_FROM=99 HESS_NO_PAIR=1 HESS_STREAM_ROWS=12"
-V2="HESS_COPIER=hip HESS_DESC_XCD=0 HESS_DESC_XCD=3 HESS_NO_TOP_FUSION=1 HESS_NO_FIRST_FUSION=1 HESS_NO_PRIME_BATCH=1 HESS_MIRROR_MAX_MB=0 HESS_DESC_PARTS=3"
+V2="HESS_PX_BAND=64 HESS_COPIER=hip HESS_DESC_XCD=0 HESS_DESC_XCD=3 HESS_NO_TOP_FUSION=1 HESS_NO_FIRST_FUSION=1 HESS_NO_PRIME_BATCH=1 HESS_MIRROR_MAX_MB=0 HESS_DESC_PARTS=3"
 case "$PART" in 1) VS="$V1";; 2) VS="$V2";; *) VS="$V1 $V2";; esac
 echo "== $(date -u +%FT%TZ) kernel sources $(python3 -c 'from hessgpu_amd import build; print(build.sources_digest())' 2>/dev/null || echo unknown) (commit $(git rev-parse --short HEAD 2>/dev/null || echo 'n/a on the GPU box')) part $PART" >> $LOG
 for v in $VS; do
