@@ -99,7 +99,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 }
 
 __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan& fs, const RawKey* list, const int* list_total,
-                                                   int cap_list, const int* ocount, int b, int nimg) {
+                                                   int cap_list, const int* ocount, int b, int nimg, int chunk, int nchunk) {
   const LimitParams& lp = fs.lp;
   const int multi = fs.multi, cap_feat = fs.cap_feat;
   int* const foffset = fs.foffset; int* const fsrc = fs.fsrc; int* const feat_total = fs.feat_total;
@@ -110,8 +110,31 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
   __shared__ int carry;
   const int tid = threadIdx.x, NTH = blockDim.x;
   const int n = list_total[b];
+  // The level totals are only read by the -tc1 / -tc2 rules on the expanded counts (below): without one, no keypoint's
+  // level is loaded (4 bytes of a 32-byte record each: 2 MB of sectors through one CU for the 65 536 keypoints of a
+  // 4096^2 image) and the image's list is split over the launch's `nchunk` workgroups.  A workgroup needs the number of
+  // features before its chunk: it adds up the counts of the keypoints before it itself (coalesced, <= 256 KB) -- no
+  // workgroup waits for another, and the last chunk's workgroup knows the image's total.  With a rule: one workgroup.
+  const bool need_levels = multi && lp.threshold > 0 && lp.method != 3;
+  if (need_levels) nchunk = 1;
+  if (chunk >= nchunk) return;
+  const int clen = (((n + nchunk - 1) / nchunk) + 1023) & ~1023;
+  const int c0 = min(n, chunk * clen), c1 = min(n, c0 + clen);
+  const int lane = tid & 63, wv = tid >> 6, nwv = NTH >> 6;
   for (int i = tid; i < g.nlev; i += NTH) lc[i] = 0;
-  if (tid == 0) carry = 0;
+  {
+    int before = multi ? 0 : c0;
+    if (multi && c0 > 0) {  // (workgroup-uniform)
+      int part = 0;
+      for (int k = tid; k < c0; k += NTH) part += ocount[(long long)b * cap_list + k];
+      part = wave_inclusive_scan(part);
+      if (lane == 63) lds[wv] = part;
+      __syncthreads();
+      for (int w = 0; w < nwv; w++) before += lds[w];
+      __syncthreads();
+    }
+    if (tid == 0) carry = before;
+  }
   __syncthreads();
   // A pass covers NTH * FC keypoints (16 384 with 1024 threads): wavefront w takes the 64 * FC consecutive keypoints
   // [w * 64 * FC, ...) of the pass in FC steps of 64 -- lane = keypoint, so every load and store of a step is coalesced
@@ -120,9 +143,8 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
   // image on the one CU this workgroup runs on).  Counts are scanned inside the wavefront (DPP), the wavefronts' totals
   // through LDS, and the level totals take one LDS atomic per step unless the step straddles a level boundary.
   constexpr int FC = 16;
-  const int lane = tid & 63, wv = tid >> 6, nwv = NTH >> 6;
-  for (int base = 0; base < n; base += NTH * FC) {
-    const int npass = min(n - base, NTH * FC);
+  for (int base = c0; base < c1; base += NTH * FC) {
+    const int npass = min(c1 - base, NTH * FC);
     const int fc = (npass + NTH - 1) / NTH;  // steps per wavefront in this pass (a short list is spread over all wavefronts)
     int cc[FC], ex[FC], tot[FC], wsum = 0;
 #pragma unroll
@@ -131,12 +153,12 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
       const bool in = u < fc && k < npass;
       const long long at = (long long)b * cap_list + base + (in ? k : 0);
       cc[u] = in ? (multi ? ocount[at] : 1) : 0;
-      const int lv = in ? list[at].level_index : 0;
       const int inc = wave_inclusive_scan(cc[u]);
       ex[u] = inc - cc[u];
       tot[u] = __builtin_amdgcn_readlane(inc, 63);
       wsum += tot[u];
-      if (tot[u]) {  // (wavefront-uniform)
+      if (need_levels && tot[u]) {  // (wavefront-uniform)
+        const int lv = in ? list[at].level_index : 0;
         const int lv0 = __builtin_amdgcn_readfirstlane(lv);
         if (__builtin_amdgcn_ballot_w64(cc[u] != 0 && lv != lv0) == 0) {
           if (lane == 0) atomicAdd(&lc[lv0], tot[u]);
@@ -170,6 +192,7 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
     if (tid == 0) carry += ptot;
     __syncthreads();
   }
+  if (chunk != nchunk - 1) return;  // (the last chunk's workgroup: `carry` is the image's total)
   if (tid == 0) {
     int total = carry, first = 0;
     // LimitFeatureCount(1) (SiftPyramid.cpp:143,201-278): only after the multi-orientation reshape
@@ -210,7 +233,7 @@ __device__ __forceinline__ void feature_scan_image(const Geom& g, const FeatScan
 
 __global__ __launch_bounds__(1024) void feature_scan_kernel(Geom g, FeatScan fs, const RawKey* list, const int* list_total,
                                                             int cap_list, const int* ocount) {
-  feature_scan_image(g, fs, list, list_total, cap_list, ocount, (int)blockIdx.x, (int)gridDim.x);
+  feature_scan_image(g, fs, list, list_total, cap_list, ocount, (int)blockIdx.y, (int)gridDim.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ================================= orientation ===============================================
@@ -1181,7 +1204,9 @@ void launch_feature_scan(hipStream_t st, const Geom& g, const LimitParams& lp, i
   FeatScan fs;
   fs.lp = lp; fs.multi = multi; fs.foffset = foffset; fs.fsrc = fsrc; fs.feat_total = feat_total; fs.feat_first = feat_first;
   fs.cap_feat = cap_feat; fs.overflow = overflow; fs.img_base = img_base; fs.host_small = host_small;
-  hipLaunchKernelGGL(feature_scan_kernel, dim3(batch), dim3(1024), 0, st, g, fs, list, list_total, cap_list, ocount);
+  // chunks of >= 4096 keypoints of an image's list, one workgroup each (see feature_scan_image)
+  const int nchunk = std::min(16, std::max(1, cap_list / 4096));
+  hipLaunchKernelGGL(feature_scan_kernel, dim3(nchunk, batch), dim3(1024), 0, st, g, fs, list, list_total, cap_list, ocount);
 }
 
 void launch_descriptor(hipStream_t st, const Geom& g, const DescParams& dp, const RawKey* list,
