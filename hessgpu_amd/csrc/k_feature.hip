@@ -913,6 +913,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom g, DescParams dp, 
 constexpr int PX_COPIES = HESS_PX_COPIES;  // (A/B builds: -DHESS_PX_COPIES=2|8, -DHESS_PX_UNROLL=1|3; same call, descriptor ms per step of 8: 2 copies 0.230, 4: 0.226, 8: 0.269 -- with eight the LDS footprint holds the kernel at four wavefronts per SIMD -- 16: 0.50)
 constexpr int PX_COPY_U64 = 128 + 4;
 constexpr int PX_WAVE_U64 = PX_COPIES * PX_COPY_U64;
+#ifndef HESS_PX_WAVES
+#define HESS_PX_WAVES 7
+#endif
+constexpr int PX_WAVES = HESS_PX_WAVES;  // wavefronts per SIMD the register allocation aims at (= workgroups per CU the LDS admits)
 constexpr float PX_SPAN_EPS = 0.02f;
 constexpr int PX_BAND_MAX = 4096;  // pixels of a raster band (dp.px_band) at most: 64 steps, one word of row-start bits per lane
 
@@ -930,7 +934,7 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // (amdgpu_waves_per_eu(7, 7): 23 040 bytes of LDS per workgroup admit seven workgroups per CU; left alone the register
 // allocator takes 77 registers = six wavefronts per SIMD.  71 registers, nothing spilled, launch 86.6 -> 85.1 us.)
 template <bool HOST_MIRROR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX_WAVES, PX_WAVES))) void descriptor_pixel_kernel(Geom g, DescParams dp, const RawKey* list,
                                                                int cap_list, const FRec* recs,
                                                                const int* fsrc, const int* feat_total,
                                                                const int* feat_first, const int* img_base,
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     for (int i = lane; i < PX_WAVE_U64 / 2; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   // LDS byte address of the lane's copy, as a float (stage B adds the word's offset in floating point)
-  const float mycopy_f = (float)(unsigned)(unsigned long long)(lds_u64*)(sums + (lane & (PX_COPIES - 1)) * PX_COPY_U64);
+  const float mycopy_f = (float)(unsigned)(unsigned long long)(lds_u64*)(sums + (lane % PX_COPIES) * PX_COPY_U64);
   const uint32_t theta_end_bits = dp.dynamic_indexing ? 0x41000001u : 0x41000000u;  // 8.0f, or the next float (admits theta == 8)
 
   // feature order: as descriptor_kernel (largest footprints first, blocks of consecutive features per XCD)
