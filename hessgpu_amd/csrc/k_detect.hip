@@ -816,13 +816,20 @@ __device__ void row_scan_block(const Geom& g, const LimitParams& lp, const int* 
 
 // List order.  The unordered detections of image b -- the tasks' slots (task_count[t] of DT_SLOTS in use) and the spill
 // list -- are copied to their places in the raw list: position = exclusive offset of the detection's row in list order +
-// number of detections of that row to its left (mask bits below its column).  Workgroups take chunks of 1024 store
+// number of detections of that row to its left (mask bits below its column).  Workgroups take chunks of PL_CHUNK (2048) store
 // positions in ARRIVAL order (ticket); the first to arrive scans the image's row counts (row_scan_block) and raises the
 // image's flag, the others load their records and count their mask bits meanwhile and then wait for the flag -- a
 // bounded, sleeping wait on a workgroup that is running by construction (it drew its ticket first); a flag that never
 // comes ends as a device-side error word the host reports (overflow[2], as topk_select_kernel), not as a hung stream.
 // ticket / flag arrive zeroed.
 constexpr int PL_SPIN_LIMIT = 1 << 21;
+#ifndef HESS_PL_PER
+#define HESS_PL_PER 2
+#endif
+// (1 / 2 / 4 / 8 positions per thread, same call: launch 72.8 / 62.7 / 63.6 / 87.8 us, pipelined line 22.37 / 22.57 / 22.27 / 21.72
+// Gpix/s -- with one, the waiting workgroups of eight images fill every wavefront slot of the chip while the first ones scan)
+constexpr int PL_PER = HESS_PL_PER;        // store positions per thread
+constexpr int PL_CHUNK = 1024 * PL_PER;  // ... per workgroup
 
 __global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams lp, DetectStore ds, const uint64_t* rowmask,
                                                              const int* rowcnt, int* rowoff, int* level_count, int* raw_total,
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams
   const int ck = s_ck;
   const int nslot = ds.ntask * DT_SLOTS;
   const int total = nslot + min(ds.spill_count[b], ds.cap_spill);
-  if (ck != 0 && ck * 1024 >= total) return;  // (workgroup-uniform) nothing in this chunk; nobody waits for it
+  if (ck != 0 && ck * PL_CHUNK >= total) return;  // (workgroup-uniform) nothing in this chunk; nobody waits for it
   if (ck == 0) {
     row_scan_block(g, lp, rowcnt, rowoff, level_count, raw_total, cap_raw, overflow, b);
     __threadfence();  // the offsets and level totals, before the flag
@@ -880,7 +887,9 @@ __global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams
       dst[1] = p.rb;
     }
   };
-  const Pending first = fetch(ck * 1024 + tid);
+  Pending first[PL_PER];
+#pragma unroll
+  for (int u = 0; u < PL_PER; u++) first[u] = fetch(ck * PL_CHUNK + u * 1024 + tid);
   if (ck != 0) {
     // ONE thread of the workgroup polls, with plain coherent loads (an ACQUIRE load per poll invalidates the cache the
     // scanning workgroup is working from, and sixteen polling wavefronts per workgroup crowd the path the scan's own
@@ -899,8 +908,10 @@ __global__ __launch_bounds__(1024) void extrema_place_kernel(Geom g, LimitParams
     __syncthreads();
     if (!s_ok) return;
   }
-  place(first);
-  for (int i = ck * 1024 + tid + gridDim.x * 1024; i < total; i += gridDim.x * 1024) place(fetch(i));  // (a spill list that outgrows the grid: rare)
+#pragma unroll
+  for (int u = 0; u < PL_PER; u++) place(first[u]);
+  for (int i0 = (ck + (int)gridDim.x) * PL_CHUNK; i0 < total; i0 += gridDim.x * PL_CHUNK)  // (a spill list that outgrows the grid: rare)
+    for (int u = 0; u < PL_PER; u++) place(fetch(i0 + u * 1024 + tid));
 }
 
 // =============================== top-K =======================================================
@@ -1153,7 +1164,7 @@ void launch_extrema_place(hipStream_t st, const Geom& g, const LimitParams& lp, 
                           const int* rowcnt, int* rowoff, int* level_count, int* raw_total, int* overflow, int* ticket,
                           int* flag, RawKey* raw, int cap_raw, int batch) {
   // the tasks' slots + a spill list of up to 16 chunks at a time (longer spill lists take more trips: they are rare)
-  const int chunks = (ds.ntask * DT_SLOTS + std::min(ds.cap_spill, 16 * 1024) + 1023) / 1024;
+  const int chunks = (ds.ntask * DT_SLOTS + std::min(ds.cap_spill, 16 * 1024) + PL_CHUNK - 1) / PL_CHUNK;
   hipLaunchKernelGGL(extrema_place_kernel, dim3(chunks, batch), dim3(1024), 0, st, g, lp, ds, rowmask, rowcnt, rowoff,
                      level_count, raw_total, overflow, ticket, flag, raw, cap_raw);
 }
