@@ -1053,7 +1053,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX_WAVES, P
       T = __builtin_amdgcn_readlane(incl, 63);
       const uint64_t ne = __builtin_amdgcn_ballot_w64(len > 0);
       const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
+      // (dl[wv] is also the float staging area of the feature's end: wavefront fences keep the compiler from moving the
+      // 64-bit accesses across the float ones, which type-based alias analysis would allow; they emit no instruction)
       unsigned long long* const starts = reinterpret_cast<unsigned long long*>(&dl[wv][0]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       starts[lane] = 0ull;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1065,6 +1068,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX_WAVES, P
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const unsigned long long mw = starts[lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       mword_lo = (uint32_t)mw; mword_hi = (uint32_t)(mw >> 32);
     }
     const int nit = (T + 63) >> 6;
