@@ -64,6 +64,23 @@ struct FirstArgs {
   float* dst0;
 };
 
+// A 16-byte LDS read the compiler keeps whole.  The horizontal passes read a row window of 16-byte groups of which the
+// first and last are only partly used; left to itself the compiler narrows the loads to what the packed FMAs take (8-byte
+// pairs at odd dword offsets: ds_read2_b32 / ds_read2_b64, 128 B per clock and banked modulo 32 dwords, where this kernel's
+// 32-byte lane pitch collides three and four ways).  The empty asm makes the whole group a used value: ds_read_b128,
+// 256 B per clock, banked modulo 64 (profiles/r06_experiments/gauss_lds.txt).
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int NGRP>
+__device__ __forceinline__ void lds_read_groups(const float* p, float (&win)[NGRP * 4]) {
+  v4f q[NGRP];
+#pragma unroll
+  for (int i = 0; i < NGRP; i++) q[i] = *reinterpret_cast<const v4f*>(p + 4 * i);
+#pragma unroll
+  for (int i = 0; i < NGRP; i++) asm volatile("" : "+v"(q[i]));
+#pragma unroll
+  for (int i = 0; i < NGRP; i++) { win[4 * i] = q[i].x; win[4 * i + 1] = q[i].y; win[4 * i + 2] = q[i].z; win[4 * i + 3] = q[i].w; }
+}
+
 __device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i < 0 || i >= n) ? 0.0f : p[i]; }
 
 // LDS floats of one tile: (32 + 2R) staged rows of 64 + 2*R4 (+4 pad) columns; a TOP tile stages one more row above
@@ -72,11 +89,19 @@ __device__ __forceinline__ float gtex1(const float* p, int n, int i) { return (i
 // A FIRST tile (R0 > 0: level 0 from u8 pixels in LDS, then level 1 from it) has the pixel window instead -- (32 + 2R + 2R0)
 // rows of 64 + 2 (R4 + R0 rounded up to 4) (+4) columns, inside which the level-0 window takes shape in place -- and the wrap
 // columns of level 0.
+#ifndef HESS_GAUSS_PAD
+#define HESS_GAUSS_PAD 4
+#endif
+#ifndef HESS_FIRST_PAD
+#define HESS_FIRST_PAD 4
+#endif
+constexpr int kRowPad = HESS_GAUSS_PAD;        // dwords between the staged rows of a tile (a multiple of 4: 16-byte accesses)
+constexpr int kFirstRowPad = HESS_FIRST_PAD;   // ... of a FIRST tile's pixel window
 template <int R, bool TOP = false, int R0 = 0>
 constexpr int gauss_tile_lds() {
-  return TOP ? (TH + 2 * R + 2) * (TW + 2 * ((R + 1 + 3) & ~3) + 4) + ((2 * (TH + 2 + 2 * R) + 2 * (TH + 2) + 3) & ~3)
-             : (R0 > 0 ? (TH + 2 * R + 2 * R0) * (TW + 2 * (((R + 3) & ~3) + ((R0 + 3) & ~3)) + 4) + ((2 * (TH + 2 + 2 * R0) + 2 * (TH + 2) + 3) & ~3)
-                       : (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + 4));
+  return TOP ? (TH + 2 * R + 2) * (TW + 2 * ((R + 1 + 3) & ~3) + kRowPad) + ((2 * (TH + 2 + 2 * R) + 2 * (TH + 2) + 3) & ~3)
+             : (R0 > 0 ? (TH + 2 * R + 2 * R0) * (TW + 2 * (((R + 3) & ~3) + ((R0 + 3) & ~3)) + kFirstRowPad) + ((2 * (TH + 2 + 2 * R0) + 2 * (TH + 2) + 3) & ~3)
+                       : (TH + 2 * R) * (TW + 2 * ((R + 3) & ~3) + kRowPad));
 }
 
 // One 64x32 tile of one level: the body of gauss_kernel, and of either half of gauss_pair_kernel.  `block` = the
@@ -107,14 +132,14 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
   constexpr int R4 = (R + RTOP + 3) & ~3;
   constexpr int OFF = R4 - R;
   constexpr int SW = TW + 2 * R4;
-  constexpr int SWP = SW + 4;          // SW % 8 == 0 -> row stride = 4 (mod 8) dwords
+  constexpr int SWP = SW + kRowPad;    // SW % 8 == 0 -> row stride = 4 (mod 8) dwords
   constexpr int ROWS = TH + 2 * R + 2 * RTOP;
   constexpr int NG = SW / 4;           // 16-byte groups per staged row
   constexpr int NV = (OFF + 8 + 2 * R + 3) / 4;
   constexpr int NWH = TH + 2 + 2 * R;  // TOP: horizontally filtered values per wrap column
   // FIRST: the pixel window A behind the level-0 window s
   constexpr int R0P = (R0 + 3) & ~3;           // column halo of level 0's horizontal pass, in whole 16-byte groups
-  constexpr int AROWS = ROWS + 2 * R0, ASW = SW + 2 * R0P, ASWP = ASW + 4, ANG = ASW / 4;
+  constexpr int AROWS = ROWS + 2 * R0, ASW = SW + 2 * R0P, ASWP = ASW + kFirstRowPad, ANG = ASW / 4;
   constexpr int NWH0 = TH + 2 + 2 * R0;
   static_assert((FIRST ? AROWS * ASWP + ((2 * NWH0 + 2 * (TH + 2) + 3) & ~3)
                        : ROWS * SWP + (TOP ? ((2 * NWH + 2 * (TH + 2) + 3) & ~3) : 0)) == gauss_tile_lds<R, TOP, R0>(), "LDS size");
@@ -226,11 +251,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
         if (task < AROWS * TPR) {
           const int r = task / TPR, xb = (task - r * TPR) * 8;
           float win[NV0 * 4];
-#pragma unroll
-          for (int i = 0; i < NV0; i++) {
-            const float4 q = *reinterpret_cast<const float4*>(&A[r * ASWP + xb + 4 * i]);
-            win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
-          }
+          lds_read_groups<NV0>(&A[r * ASWP + xb], win);
 #pragma unroll
           for (int j = 0; j < 8; j++) acc0[k][j] = 0.0f;
 #pragma unroll
@@ -504,11 +525,7 @@ __device__ __forceinline__ void gauss_tile(const GaussArgs& a, float* __restrict
       if (task < ROWS * (TW / 8)) {
         const int r = task >> 3, xb = (task & 7) * 8;
         float win[NV * 4];
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-          float4 q = *reinterpret_cast<const float4*>(&ws[r * LSWP + xb + 4 * i]);
-          win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
-        }
+        lds_read_groups<NV>(&ws[r * LSWP + xb], win);
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[k][j] = 0.0f;
 #pragma unroll
