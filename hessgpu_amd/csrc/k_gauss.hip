@@ -879,11 +879,7 @@ __global__ __launch_bounds__(CNT) void gauss_chain_kernel(ChainArgs a) {
       live[k] = t < NTASK && r >= row_lo && r <= row_hi && c0 + 3 >= col_lo && c0 <= col_hi;
       if (live[k]) {
         float win[NV * 4];
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-          const float4 q = *reinterpret_cast<const float4*>(&Sg[r * STRIDE + c0 - RU + 4 * i]);
-          win[4 * i] = q.x; win[4 * i + 1] = q.y; win[4 * i + 2] = q.z; win[4 * i + 3] = q.w;
-        }
+        lds_read_groups<NV>(&Sg[r * STRIDE + c0 - RU], win);
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[k][j] = 0.0f;
 #pragma unroll
