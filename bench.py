@@ -44,6 +44,7 @@ Added to the contract's JSON line (rank 0; N = 1 unless noted):
                       rank 0's host cores on a bounded sample of the same workload
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -334,10 +335,15 @@ def main():
     if stamps is not None:
         del stamps[:]
         host_submit[0], host_submit[1] = 0.0, 0
+    # (the interpreter's cyclic collector stays out of the timed steps: a full collection with torch imported takes
+    # milliseconds, a fifth of the driver's 20-step region when it falls inside)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     counts = run_steps(args.steps, submit_resident)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if stamps is not None:
         gaps = [stamps[0] - t0] + [b - a for a, b in zip(stamps, stamps[1:])]
         print("bench.py: completion gaps of the timed steps (ms):", " ".join(f"{g * 1e3:.2f}" for g in gaps), file=sys.stderr)
